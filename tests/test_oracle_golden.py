@@ -1,0 +1,160 @@
+"""CPU: the oracle (oracle/lavender_ref.py) against golden vectors captured from the real
+reference (tests/golden/make_goldens.py).  Tolerances: integer paths bit-exact; fp32 <= 1e-5
+on logits (T1 of SURVEY.md section 8c)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lavender_ref as R
+from tests.helpers import make_batch, sub, stats, BERT_CFGS
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def test_get_window_size(golden_dir):
+    g = _load(golden_dir, "ints")
+    for c, o in zip(g["gws_in"], g["gws_out"]):
+        w, s = R.use_window(tuple(c[0]), tuple(c[1]), tuple(c[2]))
+        assert (list(w), list(s)) == (list(o[0]), list(o[1]))
+
+
+@pytest.mark.parametrize("win", [(8, 7, 7), (8, 12, 12)])
+def test_relative_position_index(golden_dir, win):
+    g = _load(golden_dir, "ints")
+    idx = R.rel_pos_index(win).numpy().astype(np.int64)
+    tag = "x".join(map(str, win))
+    assert hashlib.sha256(idx.tobytes()).hexdigest() == str(g[f"rpi_{tag}_sha"])
+    assert (idx[:50, :50] == g[f"rpi_{tag}_corner"]).all()
+
+
+@pytest.mark.parametrize("case", [(5, 56, 56, (5, 7, 7), (0, 3, 3)), (5, 14, 14, (5, 7, 7), (0, 3, 3)),
+                                  (5, 96, 96, (5, 12, 12), (0, 6, 6)), (16, 14, 14, (8, 7, 7), (4, 3, 3)),
+                                  (5, 21, 21, (5, 7, 7), (0, 3, 3))])
+def test_shift_mask(golden_dir, case):
+    g = _load(golden_dir, "ints")
+    D, H, W, win, sh = case
+    mk = R.shift_mask(D, H, W, win, sh)
+    tag = f"{D}_{H}_{W}_" + "x".join(map(str, win)) + "_" + "x".join(map(str, sh))
+    assert list(mk.shape) == list(g[f"mask_{tag}_shape"])
+    bits = (mk != 0).numpy()
+    assert set(np.unique(mk.numpy()).tolist()) <= {-100.0, 0.0}
+    assert hashlib.sha256(np.packbits(bits).tobytes()).hexdigest() == str(g[f"mask_{tag}_sha"])
+
+
+@pytest.mark.parametrize("seed", [88, 0, 1])
+@pytest.mark.parametrize("BX", [(2, 33), (8, 32), (32, 32)])
+def test_masking_bit_exact(golden_dir, seed, BX):
+    g = _load(golden_dir, "ints")
+    B, X = BX
+    tin = torch.from_numpy(g[f"masking_s{seed}_B{B}_X{X}_in"])
+    torch.manual_seed(seed)
+    txt, ans = R.masking(tin)
+    assert (txt.numpy() == g[f"masking_s{seed}_B{B}_X{X}_txt"]).all()
+    assert (ans.numpy() == g[f"masking_s{seed}_B{B}_X{X}_ans"]).all()
+
+
+def test_masking_known_answer(golden_dir):
+    # seed 88 masks {5,14} in row 0 and {5,9,12} in row 1
+    g = _load(golden_dir, "ints")
+    txt = torch.tensor([[101] + list(range(2000, 2020)) + [102] + [0] * 10 + [103]] * 2)
+    torch.manual_seed(88)
+    _, ans = R.masking(txt)
+    assert (ans.numpy() == g["masking_appC_ans"]).all()
+    assert sorted(torch.nonzero(ans[0] != -1).flatten().tolist()) == [5, 14]
+    assert sorted(torch.nonzero(ans[1] != -1).flatten().tolist()) == [5, 9, 12]
+
+
+def test_vtm_pairs_known_answer():
+    np.random.seed(88)
+    vi, ti, tr = R.vtm_pairs(4, 4)
+    assert ti.reshape(4, 4)[:, 1:].tolist() == [[2, 3, 1], [3, 0, 2], [3, 1, 0], [0, 1, 2]]
+    assert tr.reshape(4, 4)[:, 0].all() and not tr.reshape(4, 4)[:, 1:].any()
+
+
+def test_lr_schedule(golden_dir):
+    g = _load(golden_dir, "ints")
+    lrs = [max(1e-8, 2e-5 * R.warmup_linear_factor(s, 100)) for s in range(110)]
+    np.testing.assert_allclose(lrs, g["lr_max_iter100_lr2e-5"], rtol=1e-12)
+
+
+def test_param_groups_and_state_spec(golden_dir):
+    g = _load(golden_dir, "agent")
+    t = _load(golden_dir, "tiny2l_b2")
+    spec = R.state_spec("tiny", layers=2)
+    ref_shapes = dict(zip(t["keys"].tolist(), t["shapes"].tolist()))
+    for k, s in spec.items():
+        assert str(tuple(s)) == ref_shapes[k], k
+    extra = set(ref_shapes) - set(spec)
+    assert all(k.endswith("relative_position_index") or k == "fc_mtm.predictions.decoder.bias" for k in extra)
+    for i in range(4):
+        for n in g[f"group{i}"].tolist():
+            assert R.param_group_of(n) == i, n
+    assert g["group_sizes"].tolist() == [81, 23, 90, 27]
+
+
+def _run_case(golden_dir, name, with_grads):
+    g = _load(golden_dir, name)
+    swin, bert, B, S, heads = g["meta"].tolist()
+    B, S, heads = int(B), int(S), int(heads)
+    bc = BERT_CFGS[bert]
+    P = R.filled_params(swin, hidden=bc["hidden"], layers=bc["layers"], ffn=bc["ffn"], vocab=bc["vocab"])
+    if with_grads:
+        for k, v in P.items():
+            v.requires_grad_(True)
+    batch = make_batch(B, S=S, vocab=bc["vocab"])
+    torch.manual_seed(88)
+    batch["txt"], batch["ans_mtm"] = R.masking(batch["txt"])
+    assert (batch["txt"].numpy() == g["txt"]).all() and (batch["ans_mtm"].numpy() == g["ans_mtm"]).all()
+    np.random.seed(88)
+    taps = {}
+    out = R.pretrain_forward(P, batch, swin, heads, taps=taps)
+    assert (out["ans_vtm"].numpy() == g["ans_vtm"]).all()
+    cols = torch.from_numpy(g["cols"])
+    np.testing.assert_allclose(out["out_mtm"][:, :, cols].detach().numpy(), g["out_mtm_cols"], atol=1e-5)
+    np.testing.assert_allclose(out["out_vtm"][:, :, cols].detach().numpy(), g["out_vtm_cols"], atol=1e-5)
+    np.testing.assert_allclose(torch.logsumexp(out["out_mtm"], -1).detach().numpy(), g["out_mtm_lse"], atol=1e-5)
+    assert (out["out_mtm"].argmax(-1).numpy() == g["out_mtm_argmax"]).mean() > 0.999
+    np.testing.assert_allclose(sub(taps["f_img"]), g["f_img_sub"], atol=1e-5)
+    np.testing.assert_allclose(sub(taps["f_txt"]), g["f_txt_sub"], atol=1e-5)
+    for k in ("patch_embed", "stage0", "stage1", "stage2", "stage3"):
+        np.testing.assert_allclose(sub(taps[k]), g[f"tap_{k}_sub"], atol=2e-5)
+        np.testing.assert_allclose(stats(taps[k]), g[f"tap_{k}_stats"], rtol=1e-4, atol=1e-6)
+    l_mtm, l_vtm = R.pretrain_loss(out)
+    np.testing.assert_allclose([l_mtm.item(), l_vtm.item()], g["loss"], atol=1e-5)
+    if with_grads:
+        (l_mtm + l_vtm).backward()
+        ref = dict(zip(g["grad_norm_keys"].tolist(), g["grad_norm_vals"].tolist()))
+        for k, v in ref.items():
+            if v < 0:
+                assert P[k].grad is None, k                 # emb_task, enc_img.emb_odr: unused
+            else:
+                assert abs(P[k].grad.double().norm().item() - v) <= 1e-4 * v + 1e-7, k
+        for k in g.files:
+            if k.startswith("grad_sub::"):
+                np.testing.assert_allclose(sub(P[k[10:]].grad, 2048), g[k], atol=1e-6, rtol=1e-3)
+
+
+def test_micro_forward_backward(golden_dir):
+    _run_case(golden_dir, "micro_b2", True)
+
+
+def test_micro_b5_forward(golden_dir):
+    _run_case(golden_dir, "micro_b5", False)
+
+
+def test_tiny2l_forward_backward(golden_dir):
+    _run_case(golden_dir, "tiny2l_b2", True)
+
+
+def test_swin_shapes_pad_branches(golden_dir):
+    g = _load(golden_dir, "swin_shapes")
+    P = {k: v for k, v in R.filled_params("micro", hidden=128, layers=0, ffn=512, vocab=64).items()}
+    for T, S in ((5, 64), (4, 96), (1, 224), (6, 224)):
+        x = torch.randn(1, 3, T, S, S, generator=torch.Generator().manual_seed(3))
+        y = R.swin_forward(P, "enc_img.swin", x, "micro")
+        np.testing.assert_allclose(sub(y, 2048), g[f"T{T}_S{S}_sub"], atol=2e-5)
