@@ -1,0 +1,24 @@
+# Builds the C-ABI shared library of the MI355X kernels (and the CPU-side checker pieces).
+HIPCC ?= hipcc
+ARCH  ?= gfx950
+CSRC  := lavender_amd/csrc
+OBJS  := $(CSRC)/gemm.o $(CSRC)/layernorm.o $(CSRC)/attention.o $(CSRC)/embed.o $(CSRC)/loss_optim.o $(CSRC)/runtime.o
+LIB   := lavender_amd/liblavender_hip.so
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value
+
+all: $(LIB)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/attn_common.h include/lavender_hip.h
+	$(HIPCC) $(FLAGS) -c $< -o $@
+
+$(CSRC)/runtime.o: $(CSRC)/runtime.cpp $(CSRC)/common.h include/lavender_hip.h
+	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+
+probe: $(LIB) tools/gemm_probe.cpp
+	$(HIPCC) $(FLAGS) tools/gemm_probe.cpp -o tools/gemm_probe -Llavender_amd -llavender_hip -Wl,-rpath,'$$ORIGIN/../lavender_amd'
+
+clean:
+	rm -f $(OBJS) $(LIB) tools/gemm_probe

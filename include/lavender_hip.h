@@ -1,0 +1,212 @@
+/* lavender_hip.h -- C ABI of the MI355X (gfx950) kernels behind the LAVENDER pretrain hot path.
+ *
+ * The reference (microsoft/LAVENDER) is pure Python on torch.nn: there is no FFI in it.  Each entry
+ * point below replaces the device work that a reference torch op sequence does; the reference
+ * file:line it stands in for is cited per function (paths relative to the reference root).
+ *
+ * Conventions:
+ *   - C linkage, POD arguments, no torch types.  Every function returns 0 on success or a negative
+ *     LAV_E_* code; lav_last_error() returns a message for the calling thread.  Nothing throws/exits.
+ *   - All data pointers are DEVICE pointers owned by the caller; kernels never allocate or free.
+ *   - `stream` is a hipStream_t passed as void*.  Functions only enqueue work (asynchronous), keep no
+ *     global mutable state, and may be called concurrently on different streams.
+ *   - bf16 tensors are raw uint16 bit patterns, row-major; "ld*" are leading dimensions in ELEMENTS.
+ *   - Gradient accumulators (dW, dbias, dgamma, ...) are fp32 and are ACCUMULATED INTO with atomics:
+ *     the caller zeroes them once per step (this is what lets the MTM and VTM passes share weights).
+ */
+#ifndef LAVENDER_HIP_H
+#define LAVENDER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* lav_last_error(void);
+int lav_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue.  Replaces every nn.Linear on the path (video_swin.py:73-79,137-139,
+ * 147,168,278,286; model.py:16-18,48-49; HF BertSelfAttention/BertSelfOutput/BertIntermediate/
+ * BertOutput/BertLMPredictionHead as called from model.py:242, main_pretrain_mlm.py:69,115) and
+ * their autograd backward.
+ *   layout 0 (NT): C[M,N] = A[M,K] . B[N,K]^T        y = x W^T
+ *   layout 1 (NN): C[M,N] = A[M,K] . B[K,N]          dx = dy W
+ *   layout 2 (TN): C[M,N] = A[K,M]^T . B[K,N]        dW = dy^T x   (K = token rows; `splits` > 1 allowed)
+ * Epilogue, applied in this order to v = alpha*acc:
+ *   v += bias[col]; [preact <- v]; v = gelu(v) if act==1; v *= gelu'(gelu_in) ; dropout(v);
+ *   v *= row_scale[row / rows_per_group]; v += residual; [colsum[col] += v]; store per out_mode.
+ * K-contiguous operands whose K is not a multiple of 8 must be padded with finite values up to the
+ * next multiple of 8 (their last 16-byte chunk is read whole).
+ */
+typedef struct lav_gemm_epilogue {
+    const float* bias;        /* [N] fp32 or NULL */
+    int act;                  /* 0 none, 1 exact (erf) GELU */
+    void* preact;             /* bf16 [M, ldp]: receives alpha*acc+bias before the activation, or NULL */
+    long ldp;
+    const void* gelu_in;      /* bf16 [M, ldg]: multiply by gelu'(gelu_in), or NULL */
+    long ldg;
+    float dropout_p;          /* hidden dropout (BertSelfOutput/BertOutput), mask = f(seed, row*N+col) */
+    uint32_t seed;
+    const float* row_scale;   /* per-sample stochastic-depth factor (video_swin.py:46-54), or NULL */
+    int rows_per_group;
+    const void* residual;     /* bf16 [M, ldr] or NULL */
+    long ldr;
+    float* colsum;            /* fp32 [N]: atomically accumulates the column sums of the stored values */
+    float alpha;              /* 0 is read as 1 */
+    int out_mode;             /* 0 bf16 store, 1 fp32 store, 2 fp32 atomicAdd */
+    const float* k_keep;      /* layout 2 only: contraction rows whose k_keep[row / k_rows_per_group]==0 are skipped */
+    int k_rows_per_group;
+} lav_gemm_epilogue;
+
+int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                  void* C, long ldc, const lav_gemm_epilogue* epi, int splits);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension (nn.LayerNorm at video_swin.py:209,245,282,399-403,476-478;
+ * model.py:85; HF BertEmbeddings/BertSelfOutput/BertOutput/BertPredictionHeadTransform LayerNorm).
+ *   gather_mode 0: row r of x is x + r*ldx.
+ *   gather_mode 1: PatchMerging gather (video_swin.py:271-284): logical row (b,t,h2,w2) of width 4*C0 is
+ *                  the concat [x(2h2,2w2), x(2h2+1,2w2), x(2h2,2w2+1), x(2h2+1,2w2+1)] of C0-wide source
+ *                  rows of a (BT, H, W, C0) token tensor (H, W even).
+ * mean/rstd (fp32 [rows]) are written for the backward.
+ */
+typedef struct lav_ln_gather {
+    int mode;                 /* 0 plain, 1 patch-merge 2x2 */
+    int H, W, C0;             /* source token grid (per frame) and channel count, mode 1 */
+} lav_ln_gather;
+
+int lav_layernorm_fwd(void* stream, int rows, int C, const void* x, long ldx, const lav_ln_gather* gather,
+                      const float* gamma, const float* beta, float eps, void* y, long ldy, float* mean, float* rstd);
+
+/* Backward.  dx = LNbwd(dy) [+ add_in]  (add_in: the residual-branch gradient, bf16, same layout as dx).
+ * dgamma/dbeta (fp32 [C]) are accumulated atomically.  With gather.mode==1 dx is scattered back to the
+ * (BT,H,W,C0) source layout.
+ * Optional `extra`: a second output dx2 = row_scale[row/rows_per_group] * dropout_mask(seed; row*C+col)/(1-p)
+ * * dx -- the gradient entering the dense layer that FED this residual stream (hidden dropout of
+ * BertSelfOutput/BertOutput, or the stochastic-depth factor of a Swin block) -- with its column sums
+ * accumulated into colsum (that dense layer's bias gradient). */
+typedef struct lav_ln_bwd_extra {
+    void* dx2; long lddx2;
+    const float* row_scale; int rows_per_group;
+    float dropout_p; uint32_t seed;
+    float* colsum;
+} lav_ln_bwd_extra;
+
+int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, long lddy, const void* x, long ldx,
+                      const lav_ln_gather* gather, const float* gamma, const float* mean, const float* rstd,
+                      const void* add_in, long ldadd, void* dx, long lddx, float* dgamma, float* dbeta,
+                      const lav_ln_bwd_extra* extra);
+
+/* Row-wise helper: out = row_scale[row/rpg] * gelu'(gelu_in) * dropout(seed; in), column sums into colsum.
+ * Produces a dense-branch gradient from a residual-stream gradient (inverse of the GEMM epilogue's dropout /
+ * stochastic depth / GELU).  out may be NULL (column sums only); gelu_in may be NULL. */
+int lav_scale_mask_rows(void* stream, int rows, int C, const void* in, long ldi, void* out, long ldo,
+                        const float* row_scale, int rows_per_group, float dropout_p, uint32_t seed, float* colsum,
+                        const void* gelu_in, long ldg);
+
+/* Column sums of a bf16 matrix into fp32 (bias gradients of the QKV and decoder linears). */
+int lav_colsum_bf16(void* stream, int rows, int C, const void* x, long ldx, float* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention.  One kernel family for
+ *   (a) shifted-window 3D attention: roll + window_partition + WindowAttention3D core + window_reverse
+ *       + roll back (video_swin.py:82-91,145-167,218-239,290-305) as pure index math on the un-rolled
+ *       (B,D,H,W,3C) qkv token tensor, relative-position bias gathered from the (table_rows, heads)
+ *       parameter with index = code(i)-code(j)+const, shift mask from region ids;
+ *   (b) fusion-encoder self-attention (HF BertSelfAttention eager path as called at model.py:242) with the
+ *       additive key mask (1-m)*finfo.min of model.py:239 and attention-probability dropout.
+ * qkv: bf16 (tokens, 3*heads*hd), rows ordered [q | k | v], head-major inside each (video_swin.py:147).
+ * out: bf16 (tokens, heads*hd).  lse: fp32 (problems*heads, Npad) log-sum-exp per query for the backward.
+ */
+typedef struct lav_attn_desc {
+    int mode;                 /* 0 window, 1 sequence */
+    int heads, head_dim;      /* head_dim 32 (Swin) or 64 (BERT) */
+    /* window mode: token grid and (already clamped) window / shift, video_swin.py:93-106 */
+    int B, D, H, W;
+    int wd, wh, ww, sd, sh, sw;
+    int cfg_wh, cfg_ww;       /* CONFIGURED window (h,w) extents: define the bias-table index stride (:121-135) */
+    int cfg_wd;
+    const float* bias_table;  /* fp32 ((2cfg_wd-1)(2cfg_wh-1)(2cfg_ww-1), heads) */
+    /* sequence mode */
+    int n_seq, L;
+    const int32_t* key_mask;  /* int32 (n_seq, L) 1 = attend, 0 = masked; or NULL */
+    float dropout_p; uint32_t seed;
+    float scale;              /* head_dim^-0.5 */
+} lav_attn_desc;
+
+int lav_attention_fwd(void* stream, const lav_attn_desc* d, const void* qkv, void* out, float* lse);
+/* dqkv: bf16 same layout as qkv (fully written).  dbias_table: fp32, atomically accumulated (window mode). */
+int lav_attention_bwd(void* stream, const lav_attn_desc* d, const void* qkv, const void* out, const void* dout,
+                      const float* lse, void* dqkv, float* dbias_table);
+size_t lav_attention_lse_elems(const lav_attn_desc* d);
+
+/* ---------------------------------------------------------------------------------------------
+ * Patch embedding im2col (PatchEmbed3D, video_swin.py:388-405): (B,3,T,H,W) fp32 NCDHW clip ->
+ * bf16 (B*T*(H/4)*(W/4), 96) rows [c][kt][kh][kw] with the zero frame appended at t = T (:396);
+ * the Conv3d itself is lav_gemm_bf16 on the (E, 96) flattened weight.
+ * img may be given as (B,T,3,H,W) (the EncVideo input, model.py:44) with frame_major = 1.
+ */
+int lav_patch_im2col(void* stream, const float* img, int B, int T, int H, int W, int frame_major, void* out);
+
+/* Video token assembly (EncVideo.forward, model.py:69-85): rows (b,t,0) = emb_cls, (b,t,1+p) = feat[b,t,p];
+ * + emb_pos[p'] + emb_len[t]; LayerNorm(eps) -> out row [b*seq_rows + t*(1+hw) + p'] (bf16, width Hd <= 1024).
+ * The backward recomputes the pre-LN sum from feat and the embeddings (nothing but mean/rstd is saved). */
+int lav_video_embed_fwd(void* stream, int B, int T, int hw, int Hd, const void* feat, const float* emb_cls,
+                        const float* emb_pos, const float* emb_len, const float* gamma, const float* beta, float eps,
+                        void* out, long seq_rows, float* mean, float* rstd);
+int lav_video_embed_bwd(void* stream, int B, int T, int hw, int Hd, const void* dout, long seq_rows, const void* feat,
+                        const float* emb_cls, const float* emb_pos, const float* emb_len, const float* gamma,
+                        const float* mean, const float* rstd, void* dfeat, float* d_cls, float* d_pos, float* d_len,
+                        float* dgamma, float* dbeta);
+
+/* Text embedding (HF BertEmbeddings via EncTxt.forward, model.py:125-129): word[ids] + pos[0..X) + type[0]
+ * -> LayerNorm(eps) -> dropout -> bf16 (n, X, Hd). */
+int lav_text_embed_fwd(void* stream, int n, int X, int Hd, const int64_t* ids, const float* word, const float* pos,
+                       const float* type0, const float* gamma, const float* beta, float eps, float dropout_p,
+                       uint32_t seed, void* out, float* mean, float* rstd);
+int lav_text_embed_bwd(void* stream, int n, int X, int Hd, const int64_t* ids, const void* dout, const float* word,
+                       const float* pos, const float* type0, const float* gamma, const float* mean, const float* rstd,
+                       float dropout_p, uint32_t seed, float* d_word, float* d_pos, float* d_type0, float* dgamma,
+                       float* dbeta);
+
+/* Row gather / gather-sum: builds the fusion input [video rows of sample vi | text rows of sample ti]
+ * (go_cross concat model.py:235 + VTM pairing main_pretrain_mlm.py:74-111) and its backward. */
+int lav_gather_rows(void* stream, int n_rows, int C, const void* src, long lds_, const int32_t* src_row, void* dst,
+                    long ldd);
+/* out[r] = sum_{k in [start[r], start[r+1])} src[list[k]]  (bf16 in, bf16 out, fp32 accumulate) */
+int lav_gather_sum_rows(void* stream, int n_out, int C, const void* src, long lds_, const int32_t* start,
+                        const int32_t* list, void* out, long ldo);
+
+/* ---------------------------------------------------------------------------------------------
+ * Cross entropy with ignore_index = -1, mean over labelled rows (agent.py:72, main_pretrain_mlm.py:158-163).
+ * logits: bf16 (rows, ld) with V valid columns.  Accumulates loss_sum[0] += sum_i nll_i, loss_sum[1] += #labelled
+ * (fp32, caller zeroes) and overwrites logits IN PLACE with grad_scale * (softmax - onehot); rows with label -1
+ * and the padding columns [V, ld) become 0.  grad_scale is 1/#labelled when the host knows the count (the
+ * labels are built on the host, main_pretrain_mlm.py:178-200); otherwise pass 1 and call lav_scale_by_count,
+ * which multiplies by gscale / loss_sum[1] read on the device. */
+int lav_cross_entropy_fwd_bwd(void* stream, int rows, int V, void* logits, long ld, const int64_t* labels,
+                              float* loss_sum, float grad_scale, int write_grad /* 0: loss only, logits untouched */);
+int lav_scale_by_count(void* stream, long n_elems, void* x_bf16, const float* loss_sum, float gscale);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer over the flat parameter arena (Agent_Base.backward_step, agent.py:241-250: unscale/clip by
+ * global L2 norm, AdamW with betas (0.9,0.98), per-group lr / weight decay from agent.py:96-140).
+ *   lav_sumsq: out[0] += sum g^2 (fp32).   lav_adamw_step: one fused pass over the whole arena (parameters
+ *   are laid out in execution order, 64-element aligned; block_group maps each 64-element block to one of the
+ *   four (swin|other) x (decay|no-decay) groups of agent.py:96-140):
+ *   g *= min(1, max_norm/(sqrt(sumsq)+1e-6)); p *= 1-lr*wd; m,v update; p -= lr*mhat/(sqrt(vhat)+eps);
+ *   writes the bf16 working copy used by the GEMMs. */
+int lav_sumsq_f32(void* stream, long n, const float* g, float* out);
+int lav_adamw_step(void* stream, long n, float* p, const float* g, float* m, float* v, void* p_bf16,
+                   const uint8_t* block_group /* group id (0..3) per 64-element block of the arena */,
+                   const float lr[4], const float wd[4], float beta1, float beta2, float eps, int step,
+                   const float* gradsq, float max_norm, float grad_div);
+int lav_cast_f32_to_bf16(void* stream, long n, const float* in, void* out);
+int lav_fill_droppath(void* stream, int n_blocks, int B, const float* keep_prob, uint32_t seed, float* scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

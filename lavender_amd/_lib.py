@@ -1,0 +1,91 @@
+"""ctypes binding of liblavender_hip.so (the C ABI declared in include/lavender_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent, importing
+this module raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblavender_hip.so")
+
+
+class LavenderHipError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: the MI355X kernels are not built (run `make` or __graft_entry__.build()). "
+        "lavender_amd has no CPU or eager fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint32
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [("bias", vp), ("act", i32), ("preact", vp), ("ldp", i64), ("gelu_in", vp), ("ldg", i64),
+                ("dropout_p", f32), ("seed", u32), ("row_scale", vp), ("rows_per_group", i32), ("residual", vp),
+                ("ldr", i64), ("colsum", vp), ("alpha", f32), ("out_mode", i32), ("k_keep", vp),
+                ("k_rows_per_group", i32)]
+
+
+class LnGather(C.Structure):
+    _fields_ = [("mode", i32), ("H", i32), ("W", i32), ("C0", i32)]
+
+
+class LnBwdExtra(C.Structure):
+    _fields_ = [("dx2", vp), ("lddx2", i64), ("row_scale", vp), ("rows_per_group", i32), ("dropout_p", f32),
+                ("seed", u32), ("colsum", vp)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("mode", i32), ("heads", i32), ("head_dim", i32), ("B", i32), ("D", i32), ("H", i32), ("W", i32),
+                ("wd", i32), ("wh", i32), ("ww", i32), ("sd", i32), ("sh", i32), ("sw", i32), ("cfg_wh", i32),
+                ("cfg_ww", i32), ("cfg_wd", i32), ("bias_table", vp), ("n_seq", i32), ("L", i32), ("key_mask", vp),
+                ("dropout_p", f32), ("seed", u32), ("scale", f32)]
+
+
+P = C.POINTER
+_SIGS = {
+    "lav_last_error": (C.c_char_p, []),
+    "lav_abi_version": (i32, []),
+    "lav_gemm_bf16": (i32, [vp, i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, P(GemmEpilogue), i32]),
+    "lav_layernorm_fwd": (i32, [vp, i32, i32, vp, i64, P(LnGather), vp, vp, f32, vp, i64, vp, vp]),
+    "lav_layernorm_bwd": (i32, [vp, i32, i32, vp, i64, vp, i64, P(LnGather), vp, vp, vp, vp, i64, vp, i64, vp, vp,
+                                P(LnBwdExtra)]),
+    "lav_scale_mask_rows": (i32, [vp, i32, i32, vp, i64, vp, i64, vp, i32, f32, u32, vp, vp, i64]),
+    "lav_colsum_bf16": (i32, [vp, i32, i32, vp, i64, vp]),
+    "lav_attention_fwd": (i32, [vp, P(AttnDesc), vp, vp, vp]),
+    "lav_attention_bwd": (i32, [vp, P(AttnDesc), vp, vp, vp, vp, vp, vp]),
+    "lav_attention_lse_elems": (C.c_size_t, [P(AttnDesc)]),
+    "lav_patch_im2col": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "lav_video_embed_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, i64, vp, vp]),
+    "lav_video_embed_bwd": (i32, [vp, i32, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "lav_text_embed_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, u32, vp, vp, vp]),
+    "lav_text_embed_bwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, u32, vp, vp, vp, vp, vp]),
+    "lav_gather_rows": (i32, [vp, i32, i32, vp, i64, vp, vp, i64]),
+    "lav_gather_sum_rows": (i32, [vp, i32, i32, vp, i64, vp, vp, vp, i64]),
+    "lav_cross_entropy_fwd_bwd": (i32, [vp, i32, i32, vp, i64, vp, vp, f32, i32]),
+    "lav_scale_by_count": (i32, [vp, i64, vp, vp, f32]),
+    "lav_sumsq_f32": (i32, [vp, i64, vp, vp]),
+    "lav_adamw_step": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, P(f32), P(f32), f32, f32, f32, i32, vp, f32, f32]),
+    "lav_cast_f32_to_bf16": (i32, [vp, i64, vp, vp]),
+    "lav_fill_droppath": (i32, [vp, i32, i32, vp, u32, vp]),
+}
+EXPORTS = tuple(_SIGS)
+
+for _name, (_res, _args) in _SIGS.items():
+    try:
+        _f = getattr(lib, _name)
+    except AttributeError as e:  # pragma: no cover
+        raise ImportError(f"{LIB_PATH} does not export {_name}; rebuild it") from e
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.lav_last_error()
+        raise LavenderHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

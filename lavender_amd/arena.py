@@ -1,0 +1,130 @@
+"""Flat parameter / gradient arena.
+
+MI355X-first replacement for per-tensor parameter storage: every parameter of the model lives in ONE fp32
+master buffer (in execution order, 64-element aligned), mirrored by ONE bf16 working copy (what the MFMA GEMMs
+read) and ONE fp32 gradient buffer (what the backward kernels atomically accumulate into).  Consequences:
+  * the optimizer (agent.py:241-250) is two kernel launches over the whole arena (sum of squares + fused
+    clip/AdamW/bf16 refresh) instead of ~220 per-tensor updates;
+  * data-parallel gradient exchange (agent.py:261-265) is RCCL all-reduce on contiguous slices -- buckets are
+    plain views, no flatten/unflatten copies;
+  * query/key/value weights of a BERT layer are adjacent, so the fused (2304, 768) QKV GEMM needs no concat.
+nn.Parameter objects stay the public surface (same names/shapes as the reference state_dict): their .data are
+views of the master buffer and their .grad are views of the gradient buffer.
+"""
+import re
+
+import torch
+
+from . import hip as K
+
+ALIGN = 64
+_QKV = re.compile(r"(.*attention\.self)\.(query|key|value)\.(weight|bias)$")
+
+
+def param_group_of(name):
+    """Agent_Base.build_optimizer grouping (agent.py:96-120), by substring on the unwrapped name:
+    0 swin/decay, 1 other/decay, 2 swin/no-decay, 3 other/no-decay."""
+    nd = any(s in name for s in ("bias", "LayerNorm.bias", "LayerNorm.weight"))
+    return (2 if nd else 0) + (0 if "swin." in name else 1)
+
+
+def _order(named):
+    """execution order = registration order, except q/k/v of one attention are regrouped [wq wk wv bq bk bv]."""
+    out, i = [], 0
+    named = list(named)
+    while i < len(named):
+        m = _QKV.match(named[i][0])
+        if m:
+            pre = m.group(1)
+            blk = [x for x in named[i:i + 6] if x[0].startswith(pre + ".")]
+            assert len(blk) == 6, f"unexpected attention parameter layout near {named[i][0]}"
+            d = dict(blk)
+            for kind in ("weight", "bias"):
+                for n in ("query", "key", "value"):
+                    out.append((f"{pre}.{n}.{kind}", d[f"{pre}.{n}.{kind}"]))
+            i += 6
+        else:
+            out.append(named[i])
+            i += 1
+    return out
+
+
+class ParamArena:
+    def __init__(self, module, device):
+        named = _order(module.named_parameters())
+        self.device = torch.device(device)
+        self.names, self.offsets, self.numels = [], {}, {}
+        off = 0
+        for n, p in named:
+            self.names.append(n)
+            self.offsets[n] = off
+            self.numels[n] = p.numel()
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.master = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.half = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        grp = torch.zeros(off // ALIGN, dtype=torch.uint8)
+        self.params = {}
+        for n, p in named:
+            o, k = self.offsets[n], p.numel()
+            self.master[o:o + k].copy_(p.data.reshape(-1).to(self.device, torch.float32))
+            p.data = self.master[o:o + k].view(p.shape)
+            p.grad = self.grad[o:o + k].view(p.shape)
+            p._lav16 = self.half[o:o + k].view(p.shape)
+            p._lavg = p.grad
+            p._lav_name = n
+            grp[o // ALIGN:(o + k + ALIGN - 1) // ALIGN] = param_group_of(n)
+            self.params[n] = p
+        self.block_group = grp.to(self.device)
+        self.m = None
+        self.v = None
+        self.gradsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.anchor = torch.zeros(1, dtype=torch.float32, device=self.device, requires_grad=True)
+        self.stale = True
+        self.sync_half()
+
+    # -- bf16 working copy -------------------------------------------------------------------------
+    def sync_half(self):
+        """Refresh the bf16 working copy from the fp32 master (after load_state_dict / a foreign optimizer)."""
+        K.cast_bf16(self.master, self.half, self.total)
+        self.stale = False
+
+    def sync_half_if_stale(self):
+        if self.stale:
+            self.sync_half()
+
+    def owns(self, p):
+        n = getattr(p, "_lav_name", None)
+        return n is not None and p.data_ptr() == self.master.data_ptr() + 4 * self.offsets[n]
+
+    def fused_view(self, first, rows_total):
+        """(rows_total, cols) bf16 / grad views starting at parameter `first` (adjacent q,k,v weights)."""
+        o = self.offsets[first._lav_name]
+        cols = first.shape[1] if first.dim() == 2 else 1
+        n = rows_total * cols
+        shape = (rows_total, cols) if first.dim() == 2 else (rows_total,)
+        return self.half[o:o + n].view(shape), self.grad[o:o + n].view(shape), self.master[o:o + n].view(shape)
+
+    def span(self, names):
+        """[start, end) arena range covering the given parameter names (for gradient buckets)."""
+        lo = min(self.offsets[n] for n in names)
+        hi = max(self.offsets[n] + (self.numels[n] + ALIGN - 1) // ALIGN * ALIGN for n in names)
+        return lo, hi
+
+    # -- optimizer ---------------------------------------------------------------------------------
+    def zero_grad(self):
+        self.grad.zero_()
+        for p in self.params.values():
+            if p.grad is None or p.grad.data_ptr() != p._lavg.data_ptr():
+                p.grad = p._lavg
+
+    def adamw_step(self, lr4, wd4, step, max_norm, grad_div=1.0, betas=(0.9, 0.98), eps=1e-8):
+        if self.m is None:
+            self.m = torch.zeros_like(self.master)
+            self.v = torch.zeros_like(self.master)
+        self.gradsq.zero_()
+        if max_norm > 0:
+            K.sumsq(self.grad, self.total, self.gradsq)
+        K.adamw(self.total, self.master, self.grad, self.m, self.v, self.half, self.block_group, lr4, wd4, betas[0], betas[1],
+                eps, step, self.gradsq if max_norm > 0 else None, max_norm, grad_div)

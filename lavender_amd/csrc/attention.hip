@@ -1,0 +1,678 @@
+// Flash-style attention for gfx950, forward + backward, for both attention shapes on the LAVENDER path:
+//   window mode   (Swin):  problems = (window, head), N = wd*wh*ww tokens (245 / 196 / 49 / 720), head_dim 32.
+//                 Cyclic shift, window partition/reverse are index math on the un-rolled token tensor; the
+//                 relative-position bias is gathered from an LDS copy of this head's table column with
+//                 index = code(q) - code(k) + const; the shift mask is region(q) != region(k) ? -100 : 0.
+//   sequence mode (fusion BERT): problems = (sequence, head), N = L (282 / 276 / 757), head_dim 64, key mask,
+//                 attention-probability dropout regenerated from a counter hash.
+// Score tiles are 32x32 MFMA tiles computed transposed (keys x queries) so each lane owns ONE query column:
+// softmax statistics are lane-local (plus one cross-half shuffle) and the probability tile feeds the P.V MFMA
+// as a B operand straight from registers.  K sits in LDS swizzled for ds_read_b128 A-fragments; V sits
+// row-major and is read with ds_read_b64_tr_b16 (hardware transpose) as the A operand of O^T = V^T P^T.
+#include "attn_common.h"
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+template <int HD>
+__device__ __forceinline__ int vrow_off(int row, int slot) {
+    if (HD == 32) return row * 64 + (slot << 4);
+    return row * 128 + ((slot ^ (((row >> 1) & 1) << 2)) << 4);
+}
+
+// A-operand (32 rows of the transposed tile = 32 d-values, 16 keys) from a row-major [key][HD] LDS tile.
+// lane (j = l&31 -> d = d0 + j, hi): keys key0 + {4hi..4hi+3} and key0 + 8 + {4hi..4hi+3}
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int key0, int d0, int lane) {
+    const int i = lane & 15, dhalf = (lane >> 4) & 1, hi = lane >> 5;
+    const int r = i >> 2, c = i & 3;
+    const int dcol = d0 + 16 * dhalf + 4 * c;                 // first of 4 d-columns this lane's address covers
+    const int slot = dcol >> 3, sub = (dcol & 7) * 2;
+    const int row0 = key0 + 4 * hi + r;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + vrow_off<HD>(row0, slot) + sub));
+    s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + vrow_off<HD>(row0 + 8, slot) + sub));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi4;
+    return u.v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int HD, int MODE, int KT, int KL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                                  // KL x HD bf16, K-type swizzle
+    char* Vs = Ks + KL * HD * 2;                      // KL x HD bf16, V-type layout
+    int* kinfo = (int*)(Vs + KL * HD * 2);            // KL x int32: window: code | region << 16; sequence: additive mask bits
+    float* tbl = (float*)(kinfo + KL);                // window mode: this head's bias-table column
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int prob = blockIdx.x / a.d.heads, head = blockIdx.x % a.d.heads;
+    const int N = a.N, C = a.C, ld = 3 * C;
+    const bf16_t* qkv = a.qkv;
+
+    if (MODE == 0) {
+        for (int r = tid; r < a.tbl_rows; r += 256) tbl[r] = a.d.bias_table[(long)r * a.d.heads + head];
+    }
+
+    for (int rr = 0; rr < a.R; ++rr) {
+        const int qt = (blockIdx.y * a.R + rr) * 4 + wave;
+        const bool q_active = qt < a.nqt;              // wave-uniform
+        const int q = qt * 32 + j;
+        const bool q_ok = q_active && q < N;
+        int q_row = 0, q_code = 0, q_reg = 0;
+        if (q_ok) {
+            if (MODE == 0) { TokInfo t = win_token(a, prob, q); q_row = t.row; q_code = t.code; q_reg = t.region; }
+            else q_row = prob * N + q;
+        }
+        bf16x8 qf[HD / 16];
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q_ok) v = *(const uint4*)(qkv + (long)q_row * ld + head * HD + ks * 16 + 8 * hi);
+            qf[ks] = as_bf16x8(v);
+        }
+        f32x16 o[HD / 32];
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+
+        for (int kc0 = 0; kc0 < N; kc0 += KL) {
+            // ---- stage K / V rows [kc0, kc0+KL) and the per-key info ----------------------------------
+            if (rr > 0 || kc0 > 0) __syncthreads();
+            if (rr == 0 || N > KL) {
+                constexpr int CPR = HD / 8;            // 16-byte chunks per row
+                for (int c = tid; c < KL * CPR; c += 256) {
+                    const int row = c / CPR, slot = c % CPR;
+                    const int key = kc0 + row;
+                    uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
+                    if (key < N) {
+                        int krow;
+                        if (MODE == 0) krow = win_token(a, prob, key).row; else krow = prob * N + key;
+                        const bf16_t* p = qkv + (long)krow * ld + head * HD + slot * 8;
+                        kv = *(const uint4*)(p + C);
+                        vv = *(const uint4*)(p + 2 * C);
+                    }
+                    *(uint4*)(Ks + krow_off<HD>(row, slot)) = kv;
+                    *(uint4*)(Vs + vrow_off<HD>(row, slot)) = vv;
+                }
+                for (int row = tid; row < KL; row += 256) {
+                    const int key = kc0 + row;
+                    int info = 0;
+                    if (MODE == 0) {
+                        if (key < N) { TokInfo t = win_token(a, prob, key); info = t.code | (t.region << 16); }
+                    } else {
+                        float add = 0.f;
+                        if (a.d.key_mask && key < N && a.d.key_mask[(long)prob * N + key] == 0) add = -INFINITY;
+                        info = __float_as_int(add);
+                    }
+                    kinfo[row] = info;
+                }
+            }
+            __syncthreads();
+            if (!q_active) continue;
+
+            const int kl_keys = min(KL, N - kc0);
+            for (int sc0 = 0; sc0 < kl_keys; sc0 += 32 * KT) {
+                // ---- S^T tiles: keys x queries -----------------------------------------------------
+                f32x16 s[KT];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+                    const int k0 = sc0 + kt * 32;
+                    if (k0 >= kl_keys) continue;
+#pragma unroll
+                    for (int ks = 0; ks < HD / 16; ++ks) {
+                        bf16x8 kf = *(const bf16x8*)(Ks + krow_off<HD>(k0 + j, ks * 2 + hi));
+                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                    }
+                }
+                // ---- scale + bias + mask, running max ---------------------------------------------
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const int k0 = sc0 + kt * 32;
+                    if (k0 >= kl_keys) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[kt][r] = -INFINITY;
+                        continue;
+                    }
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int kb = k0 + 8 * r4 + 4 * hi;           // 4 consecutive keys
+                        const int4 inf = *(const int4*)(kinfo + kb);
+                        const int infs[4] = {inf.x, inf.y, inf.z, inf.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = s[kt][r4 * 4 + e] * a.d.scale;
+                            if (MODE == 0) {
+                                const int kcode = infs[e] & 0xffff, kreg = infs[e] >> 16;
+                                v += tbl[q_code - kcode + a.tbl_const];
+                                if (kreg != q_reg) v += -100.0f;
+                            } else {
+                                v += __int_as_float(infs[e]);
+                            }
+                            if (kc0 + kb + e >= N) v = -INFINITY;
+                            s[kt][r4 * 4 + e] = v;
+                            mx = fmaxf(mx, v);
+                        }
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run, mx);
+                const float m_use = m_new == -INFINITY ? 0.f : m_new;
+                const float alpha = __expf(m_run - m_use);           // m_run = -inf -> 0
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                m_run = m_new;
+                // ---- P = exp(S - m), O^T += V^T P^T -------------------------------------------------
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const int k0 = sc0 + kt * 32;
+                    if (k0 >= kl_keys) continue;
+                    float p[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { p[r] = __expf(s[kt][r] - m_use); l_run += p[r]; }
+                    if (MODE == 1 && a.d.dropout_p > 0.f) {
+                        const float inv = 1.f / (1.f - a.d.dropout_p);
+                        const uint64_t base = ((uint64_t)(prob * a.d.heads + head) * (uint64_t)N + (uint64_t)q) * (uint64_t)N;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = kc0 + k0 + tile_row(r, hi);
+                            p[r] = lav_keep(a.d.seed, base + key, a.thresh) ? p[r] * inv : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        bf16x8 pf = pack_frag(p + 8 * sl);
+#pragma unroll
+                        for (int dt = 0; dt < HD / 32; ++dt) {
+                            bf16x8 vf = tr_frag<HD>(Vs, k0 + 16 * sl, dt * 32, lane);
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (!q_active) continue;
+        // ---- epilogue: O = O^T / l ---------------------------------------------------------------
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv_l = l_tot > 0.f ? 1.f / l_tot : 0.f;
+        if (q_ok) {
+            bf16_t* op = a.o_w + (long)q_row * C + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = dt * 32 + 8 * r4 + 4 * hi;
+                    uint2 w;
+                    w.x = pack2(o[dt][r4 * 4 + 0] * inv_l, o[dt][r4 * 4 + 1] * inv_l);
+                    w.y = pack2(o[dt][r4 * 4 + 2] * inv_l, o[dt][r4 * 4 + 3] * inv_l);
+                    *(uint2*)(op + d) = w;
+                }
+            if (a.lse && hi == 0) a.lse[(long)blockIdx.x * a.Npad + q] = m_run + __logf(l_tot);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, pass 1: dQ (+ relative-position-bias gradient).  Wave owns a 32-query tile, loops over keys.
+//   S^T = K Q^T ; P^T = exp(S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - delta) ; dQ^T = K^T dS^T * scale
+// delta[q] = sum_d dO[q,d] O[q,d] is computed here and stored (fp32, lse layout, second half of the lse buffer).
+// ------------------------------------------------------------------------------------------------
+template <int HD, int MODE, int KL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a, float* delta_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                                  // K-type (A operand of S^T)
+    char* Kv = Ks + KL * HD * 2;                      // V-type copy of K (tr-read A operand of dQ^T)
+    char* Vs = Kv + KL * HD * 2;                      // K-type V (A operand of dP^T)
+    int* kinfo = (int*)(Vs + KL * HD * 2);
+    float* tbl = (float*)(kinfo + KL);                // bias table column
+    float* dtbl = tbl + a.tbl_rows;                   // its gradient (LDS accumulation, flushed with atomics)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int prob = blockIdx.x / a.d.heads, head = blockIdx.x % a.d.heads;
+    const int N = a.N, C = a.C, ld = 3 * C;
+    const bf16_t* qkv = a.qkv;
+
+    if (MODE == 0) {
+        for (int r = tid; r < a.tbl_rows; r += 256) { tbl[r] = a.d.bias_table[(long)r * a.d.heads + head]; dtbl[r] = 0.f; }
+    }
+
+    for (int rr = 0; rr < a.R; ++rr) {
+        const int qt = (blockIdx.y * a.R + rr) * 4 + wave;
+        const bool q_active = qt < a.nqt;
+        const int q = qt * 32 + j;
+        const bool q_ok = q_active && q < N;
+        int q_row = 0, q_code = 0, q_reg = 0;
+        if (q_ok) {
+            if (MODE == 0) { TokInfo t = win_token(a, prob, q); q_row = t.row; q_code = t.code; q_reg = t.region; }
+            else q_row = prob * N + q;
+        }
+        bf16x8 qf[HD / 16], dof[HD / 16];
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0), g = v, ov = v;
+            if (q_ok) {
+                v = *(const uint4*)(qkv + (long)q_row * ld + head * HD + ks * 16 + 8 * hi);
+                g = *(const uint4*)(a.dout + (long)q_row * C + head * HD + ks * 16 + 8 * hi);
+                ov = *(const uint4*)(a.out + (long)q_row * C + head * HD + ks * 16 + 8 * hi);
+            }
+            qf[ks] = as_bf16x8(v); dof[ks] = as_bf16x8(g);
+            float gf[8], of[8];
+            unpack8(g, gf); unpack8(ov, of);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += gf[e] * of[e];
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        const float lse = q_ok ? a.lse[(long)blockIdx.x * a.Npad + q] : 0.f;
+        if (q_ok && hi == 0) delta_out[(long)blockIdx.x * a.Npad + q] = dl;
+
+        f32x16 dq[HD / 32];
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+        for (int kc0 = 0; kc0 < N; kc0 += KL) {
+            if (rr > 0 || kc0 > 0) __syncthreads();
+            if (rr == 0 || N > KL) {
+                constexpr int CPR = HD / 8;
+                for (int c = tid; c < KL * CPR; c += 256) {
+                    const int row = c / CPR, slot = c % CPR;
+                    const int key = kc0 + row;
+                    uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
+                    if (key < N) {
+                        int krow;
+                        if (MODE == 0) krow = win_token(a, prob, key).row; else krow = prob * N + key;
+                        const bf16_t* p = qkv + (long)krow * ld + head * HD + slot * 8;
+                        kv = *(const uint4*)(p + C);
+                        vv = *(const uint4*)(p + 2 * C);
+                    }
+                    *(uint4*)(Ks + krow_off<HD>(row, slot)) = kv;
+                    *(uint4*)(Kv + vrow_off<HD>(row, slot)) = kv;
+                    *(uint4*)(Vs + krow_off<HD>(row, slot)) = vv;
+                }
+                for (int row = tid; row < KL; row += 256) {
+                    const int key = kc0 + row;
+                    int info = 0;
+                    if (MODE == 0) {
+                        if (key < N) { TokInfo t = win_token(a, prob, key); info = t.code | (t.region << 16); }
+                    } else {
+                        float add = 0.f;
+                        if (a.d.key_mask && key < N && a.d.key_mask[(long)prob * N + key] == 0) add = -INFINITY;
+                        info = __float_as_int(add);
+                    }
+                    kinfo[row] = info;
+                }
+            }
+            __syncthreads();
+            if (!q_active) continue;
+            const int kl_keys = min(KL, N - kc0);
+            for (int k0 = 0; k0 < kl_keys; k0 += 32) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < HD / 16; ++ks) {
+                    bf16x8 kf = *(const bf16x8*)(Ks + krow_off<HD>(k0 + j, ks * 2 + hi));
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                    bf16x8 vf = *(const bf16x8*)(Vs + krow_off<HD>(k0 + j, ks * 2 + hi));
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+                }
+                float ds[16];
+                const float inv = (MODE == 1 && a.d.dropout_p > 0.f) ? 1.f / (1.f - a.d.dropout_p) : 1.f;
+                const uint64_t base = ((uint64_t)(prob * a.d.heads + head) * (uint64_t)N + (uint64_t)q) * (uint64_t)N;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int kb = k0 + 8 * r4 + 4 * hi;
+                    const int4 inf = *(const int4*)(kinfo + kb);
+                    const int infs[4] = {inf.x, inf.y, inf.z, inf.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = r4 * 4 + e;
+                        float v = s[r] * a.d.scale;
+                        int bidx = 0;
+                        if (MODE == 0) {
+                            const int kcode = infs[e] & 0xffff, kreg = infs[e] >> 16;
+                            bidx = q_code - kcode + a.tbl_const;
+                            v += tbl[bidx];
+                            if (kreg != q_reg) v += -100.0f;
+                        } else {
+                            v += __int_as_float(infs[e]);
+                        }
+                        const bool valid = q_ok && (kc0 + kb + e < N);
+                        float p = valid ? __expf(v - lse) : 0.f;
+                        float g = dp[r];
+                        if (MODE == 1 && a.d.dropout_p > 0.f)
+                            g = lav_keep(a.d.seed, base + (kc0 + kb + e), a.thresh) ? g * inv : 0.f;
+                        const float dsv = p * (g - dl);
+                        ds[r] = dsv;
+                        if (MODE == 0 && valid) atomicAdd(&dtbl[bidx], dsv);
+                    }
+                }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    bf16x8 dsf = pack_frag(ds + 8 * sl);
+#pragma unroll
+                    for (int dt = 0; dt < HD / 32; ++dt) {
+                        bf16x8 kt_ = tr_frag<HD>(Kv, k0 + 16 * sl, dt * 32, lane);
+                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt_, dsf, dq[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (q_ok) {
+            bf16_t* op = a.dqkv + (long)q_row * ld + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = dt * 32 + 8 * r4 + 4 * hi;
+                    uint2 w;
+                    w.x = pack2(dq[dt][r4 * 4 + 0] * a.d.scale, dq[dt][r4 * 4 + 1] * a.d.scale);
+                    w.y = pack2(dq[dt][r4 * 4 + 2] * a.d.scale, dq[dt][r4 * 4 + 3] * a.d.scale);
+                    *(uint2*)(op + d) = w;
+                }
+        }
+    }
+    if (MODE == 0 && a.dbias) {
+        __syncthreads();
+        for (int r = tid; r < a.tbl_rows; r += 256) {
+            const float v = dtbl[r];
+            if (v != 0.f) atomicAdd(a.dbias + (long)r * a.d.heads + head, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, pass 2: dK, dV.  Wave owns a 32-key tile, loops over queries staged in LDS.
+//   S = Q K^T (queries x keys) ; P = exp(S - lse[q]) ; dP = dO V^T ; dS = P o (dP - delta[q])
+//   dV^T = dO^T P~   (P~ = dropout(P)) ;  dK^T = Q^T dS * scale
+// ------------------------------------------------------------------------------------------------
+template <int HD, int MODE, int QL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a, const float* delta_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;                                  // K-type: A operand of S
+    char* Qv = Qs + QL * HD * 2;                      // V-type: tr-read A operand of dK^T
+    char* Gs = Qv + QL * HD * 2;                      // dO, K-type: A operand of dP
+    char* Gv = Gs + QL * HD * 2;                      // dO, V-type: tr-read A operand of dV^T
+    int* qinfo = (int*)(Gv + QL * HD * 2);            // per query: code | region << 16
+    float* qlse = (float*)(qinfo + QL);
+    float* qdl = qlse + QL;
+    float* tbl = qdl + QL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int prob = blockIdx.x / a.d.heads, head = blockIdx.x % a.d.heads;
+    const int N = a.N, C = a.C, ld = 3 * C;
+    const bf16_t* qkv = a.qkv;
+
+    if (MODE == 0) {
+        for (int r = tid; r < a.tbl_rows; r += 256) tbl[r] = a.d.bias_table[(long)r * a.d.heads + head];
+    }
+
+    for (int rr = 0; rr < a.R; ++rr) {
+        const int kt = (blockIdx.y * a.R + rr) * 4 + wave;
+        const bool k_active = kt < a.nqt;
+        const int key = kt * 32 + j;
+        const bool k_ok = k_active && key < N;
+        int k_row = 0, k_code = 0, k_reg = 0;
+        float k_add = 0.f;
+        if (k_ok) {
+            if (MODE == 0) { TokInfo t = win_token(a, prob, key); k_row = t.row; k_code = t.code; k_reg = t.region; }
+            else {
+                k_row = prob * N + key;
+                if (a.d.key_mask && a.d.key_mask[(long)prob * N + key] == 0) k_add = -INFINITY;
+            }
+        }
+        bf16x8 kf[HD / 16], vf[HD / 16];
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
+            if (k_ok) {
+                const bf16_t* p = qkv + (long)k_row * ld + head * HD + ks * 16 + 8 * hi;
+                kv = *(const uint4*)(p + C);
+                vv = *(const uint4*)(p + 2 * C);
+            }
+            kf[ks] = as_bf16x8(kv); vf[ks] = as_bf16x8(vv);
+        }
+        f32x16 dk[HD / 32], dv[HD / 32];
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+        for (int qc0 = 0; qc0 < N; qc0 += QL) {
+            if (rr > 0 || qc0 > 0) __syncthreads();
+            if (rr == 0 || N > QL) {
+                constexpr int CPR = HD / 8;
+                for (int c = tid; c < QL * CPR; c += 256) {
+                    const int row = c / CPR, slot = c % CPR;
+                    const int q = qc0 + row;
+                    uint4 qv = make_uint4(0, 0, 0, 0), gv = qv;
+                    if (q < N) {
+                        int qrow;
+                        if (MODE == 0) qrow = win_token(a, prob, q).row; else qrow = prob * N + q;
+                        qv = *(const uint4*)(qkv + (long)qrow * ld + head * HD + slot * 8);
+                        gv = *(const uint4*)(a.dout + (long)qrow * C + head * HD + slot * 8);
+                    }
+                    *(uint4*)(Qs + krow_off<HD>(row, slot)) = qv;
+                    *(uint4*)(Qv + vrow_off<HD>(row, slot)) = qv;
+                    *(uint4*)(Gs + krow_off<HD>(row, slot)) = gv;
+                    *(uint4*)(Gv + vrow_off<HD>(row, slot)) = gv;
+                }
+                for (int row = tid; row < QL; row += 256) {
+                    const int q = qc0 + row;
+                    int info = 0; float l = 0.f, dl = 0.f;
+                    if (q < N) {
+                        if (MODE == 0) { TokInfo t = win_token(a, prob, q); info = t.code | (t.region << 16); }
+                        l = a.lse[(long)blockIdx.x * a.Npad + q];
+                        dl = delta_in[(long)blockIdx.x * a.Npad + q];
+                    }
+                    qinfo[row] = info; qlse[row] = l; qdl[row] = dl;
+                }
+            }
+            __syncthreads();
+            if (!k_active) continue;
+            const int ql = min(QL, N - qc0);
+            for (int q0 = 0; q0 < ql; q0 += 32) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < HD / 16; ++ks) {
+                    bf16x8 qa = *(const bf16x8*)(Qs + krow_off<HD>(q0 + j, ks * 2 + hi));
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+                    bf16x8 ga = *(const bf16x8*)(Gs + krow_off<HD>(q0 + j, ks * 2 + hi));
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp, 0, 0, 0);
+                }
+                float pd[16], ds[16];
+                const float inv = (MODE == 1 && a.d.dropout_p > 0.f) ? 1.f / (1.f - a.d.dropout_p) : 1.f;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int qb = q0 + 8 * r4 + 4 * hi;
+                    const int4 inf = *(const int4*)(qinfo + qb);
+                    const float4 l4 = *(const float4*)(qlse + qb);
+                    const float4 d4 = *(const float4*)(qdl + qb);
+                    const int infs[4] = {inf.x, inf.y, inf.z, inf.w};
+                    const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+                    const float dls[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = r4 * 4 + e;
+                        const int q = qc0 + qb + e;
+                        float v = s[r] * a.d.scale;
+                        if (MODE == 0) {
+                            const int qcode = infs[e] & 0xffff, qreg = infs[e] >> 16;
+                            v += tbl[qcode - k_code + a.tbl_const];
+                            if (qreg != k_reg) v += -100.0f;
+                        } else {
+                            v += k_add;
+                        }
+                        const bool valid = k_ok && q < N;
+                        const float p = valid ? __expf(v - ls[e]) : 0.f;
+                        float g = dp[r], pdrop = p;
+                        if (MODE == 1 && a.d.dropout_p > 0.f) {
+                            const uint64_t idx = ((uint64_t)(prob * a.d.heads + head) * (uint64_t)N + (uint64_t)q) * (uint64_t)N + (uint64_t)key;
+                            const bool keep = lav_keep(a.d.seed, idx, a.thresh);
+                            g = keep ? g * inv : 0.f;
+                            pdrop = keep ? p * inv : 0.f;
+                        }
+                        pd[r] = pdrop;
+                        ds[r] = p * (g - dls[e]);
+                    }
+                }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    bf16x8 pf = pack_frag(pd + 8 * sl), dsf = pack_frag(ds + 8 * sl);
+#pragma unroll
+                    for (int dt = 0; dt < HD / 32; ++dt) {
+                        bf16x8 gt = tr_frag<HD>(Gv, q0 + 16 * sl, dt * 32, lane);
+                        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf, dv[dt], 0, 0, 0);
+                        bf16x8 qt_ = tr_frag<HD>(Qv, q0 + 16 * sl, dt * 32, lane);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, dsf, dk[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (k_ok) {
+            bf16_t* op = a.dqkv + (long)k_row * ld + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = dt * 32 + 8 * r4 + 4 * hi;
+                    uint2 w;
+                    w.x = pack2(dk[dt][r4 * 4 + 0] * a.d.scale, dk[dt][r4 * 4 + 1] * a.d.scale);
+                    w.y = pack2(dk[dt][r4 * 4 + 2] * a.d.scale, dk[dt][r4 * 4 + 3] * a.d.scale);
+                    *(uint2*)(op + C + d) = w;
+                    w.x = pack2(dv[dt][r4 * 4 + 0], dv[dt][r4 * 4 + 1]);
+                    w.y = pack2(dv[dt][r4 * 4 + 2], dv[dt][r4 * 4 + 3]);
+                    *(uint2*)(op + 2 * C + d) = w;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int attn_setup(const lav_attn_desc* d, AttnArgs& a, int& problems) {
+    LAV_REQUIRE(d, "attention: null descriptor");
+    memset(&a, 0, sizeof(a));
+    a.d = *d;
+    LAV_REQUIRE(d->heads > 0, "attention: heads=%d", d->heads);
+    a.C = d->heads * d->head_dim;
+    if (d->mode == 0) {
+        LAV_REQUIRE(d->head_dim == 32, "attention(window): head_dim must be 32 (got %d)", d->head_dim);
+        LAV_REQUIRE(d->wd > 0 && d->wh > 0 && d->ww > 0, "attention(window): bad window");
+        LAV_REQUIRE(d->D % d->wd == 0 && d->H % d->wh == 0 && d->W % d->ww == 0,
+                    "attention(window): token grid (%d,%d,%d) is not a multiple of the window (%d,%d,%d); the zero-pad "
+                    "branch of video_swin.py:211-215 is not supported", d->D, d->H, d->W, d->wd, d->wh, d->ww);
+        LAV_REQUIRE(d->sd < d->wd && d->sh < d->wh && d->sw < d->ww && d->sd >= 0 && d->sh >= 0 && d->sw >= 0, "attention(window): bad shift");
+        LAV_REQUIRE(d->wd <= d->cfg_wd && d->wh <= d->cfg_wh && d->ww <= d->cfg_ww, "attention(window): window exceeds configured window");
+        LAV_REQUIRE(d->bias_table, "attention(window): null bias table");
+        a.N = d->wd * d->wh * d->ww;
+        a.nWd = d->D / d->wd; a.nWh = d->H / d->wh; a.nWw = d->W / d->ww;
+        problems = d->B * a.nWd * a.nWh * a.nWw;
+        a.cstride_h = 2 * d->cfg_ww - 1;
+        a.cstride_d = (2 * d->cfg_wh - 1) * a.cstride_h;
+        a.tbl_rows = (2 * d->cfg_wd - 1) * a.cstride_d;
+        a.tbl_const = (d->cfg_wd - 1) * a.cstride_d + (d->cfg_wh - 1) * a.cstride_h + (d->cfg_ww - 1);
+        LAV_REQUIRE(a.tbl_rows < 65536, "attention(window): bias table too large");
+    } else {
+        LAV_REQUIRE(d->head_dim == 64, "attention(sequence): head_dim must be 64 (got %d)", d->head_dim);
+        LAV_REQUIRE(d->n_seq > 0 && d->L > 0, "attention(sequence): bad shape");
+        a.N = d->L;
+        problems = d->n_seq;
+    }
+    a.nqt = (a.N + 31) / 32;
+    a.Npad = a.nqt * 32;
+    a.thresh = lav_drop_thresh(d->dropout_p);
+    return LAV_OK;
+}
+
+extern "C" size_t lav_attention_lse_elems(const lav_attn_desc* d) {
+    AttnArgs a; int problems = 0;
+    if (attn_setup(d, a, problems)) return 0;
+    return (size_t)2 * problems * d->heads * a.Npad;      // lse followed by delta (backward scratch)
+}
+
+template <typename K>
+static void set_lds(K kern, size_t bytes) {
+    if (bytes > 65536) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); (void)hipGetLastError(); }
+}
+
+#define WIN_KL 256
+#define SEQ_KL 288
+
+extern "C" int lav_attention_fwd(void* stream, const lav_attn_desc* d, const void* qkv, void* out, float* lse) {
+    AttnArgs a; int problems = 0;
+    if (int rc = attn_setup(d, a, problems)) return rc;
+    LAV_REQUIRE(qkv && out, "lav_attention_fwd: null pointer");
+    a.qkv = (const bf16_t*)qkv; a.o_w = (bf16_t*)out; a.lse = lse;
+    hipStream_t s = (hipStream_t)stream;
+    const int KL = d->mode == 0 ? WIN_KL : SEQ_KL;
+    const int qgroups = (a.nqt + 3) / 4;
+    if (a.N <= KL) { a.R = qgroups; } else { a.R = 1; }
+    dim3 grid(problems * d->heads, a.N <= KL ? 1 : qgroups), block(256);
+    if (d->mode == 0) {
+        size_t lds = (size_t)WIN_KL * 32 * 2 * 2 + WIN_KL * 4 + (size_t)a.tbl_rows * 4;
+        set_lds(attn_fwd_kernel<32, 0, 8, WIN_KL>, lds);
+        hipLaunchKernelGGL((attn_fwd_kernel<32, 0, 8, WIN_KL>), grid, block, lds, s, a);
+    } else {
+        size_t lds = (size_t)SEQ_KL * 64 * 2 * 2 + SEQ_KL * 4;
+        set_lds(attn_fwd_kernel<64, 1, 3, SEQ_KL>, lds);
+        hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 3, SEQ_KL>), grid, block, lds, s, a);
+    }
+    return lav_check_launch("lav_attention_fwd");
+}
+
+#define SEQ_QL 256
+
+extern "C" int lav_attention_bwd(void* stream, const lav_attn_desc* d, const void* qkv, const void* out, const void* dout,
+                                 const float* lse, void* dqkv, float* dbias_table) {
+    AttnArgs a; int problems = 0;
+    if (int rc = attn_setup(d, a, problems)) return rc;
+    LAV_REQUIRE(qkv && out && dout && lse && dqkv, "lav_attention_bwd: null pointer");
+    a.qkv = (const bf16_t*)qkv; a.out = (const bf16_t*)out; a.dout = (const bf16_t*)dout; a.lse = (float*)lse;
+    a.dqkv = (bf16_t*)dqkv; a.dbias = dbias_table;
+    float* delta = (float*)lse + (size_t)problems * d->heads * a.Npad;
+    hipStream_t s = (hipStream_t)stream;
+    const int qgroups = (a.nqt + 3) / 4;
+    if (d->mode == 0) {
+        const bool one = a.N <= WIN_KL;
+        a.R = one ? qgroups : 1;
+        dim3 grid(problems * d->heads, one ? 1 : qgroups), block(256);
+        size_t lds1 = (size_t)WIN_KL * 32 * 2 * 3 + WIN_KL * 4 + (size_t)a.tbl_rows * 8;
+        set_lds(attn_bwd_dq_kernel<32, 0, WIN_KL>, lds1);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<32, 0, WIN_KL>), grid, block, lds1, s, a, delta);
+        size_t lds2 = (size_t)WIN_KL * 32 * 2 * 4 + WIN_KL * 12 + (size_t)a.tbl_rows * 4;
+        set_lds(attn_bwd_dkv_kernel<32, 0, WIN_KL>, lds2);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<32, 0, WIN_KL>), grid, block, lds2, s, a, (const float*)delta);
+    } else {
+        const bool one = a.N <= SEQ_KL;
+        a.R = one ? qgroups : 1;
+        dim3 grid(problems * d->heads, one ? 1 : qgroups), block(256);
+        size_t lds1 = (size_t)SEQ_KL * 64 * 2 * 3 + SEQ_KL * 4;
+        set_lds(attn_bwd_dq_kernel<64, 1, SEQ_KL>, lds1);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 1, SEQ_KL>), grid, block, lds1, s, a, delta);
+        const bool one2 = a.N <= SEQ_QL;
+        a.R = one2 ? qgroups : 1;
+        dim3 grid2(problems * d->heads, one2 ? 1 : qgroups);
+        size_t lds2 = (size_t)SEQ_QL * 64 * 2 * 4 + SEQ_QL * 12;
+        set_lds(attn_bwd_dkv_kernel<64, 1, SEQ_QL>, lds2);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 1, SEQ_QL>), grid2, block, lds2, s, a, (const float*)delta);
+    }
+    return lav_check_launch("lav_attention_bwd");
+}

@@ -1,0 +1,79 @@
+// Shared device/host helpers for the LAVENDER MI355X (gfx950 / CDNA4) kernels.
+// wave = 64 lanes everywhere; bf16 storage, fp32 arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef uint16_t bf16_t;                                   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8; // MFMA A/B operand (16x16x32, 32x32x16)
+typedef __attribute__((ext_vector_type(4))) float f32x4;   // 16x16 accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16; // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define LAV_OK 0
+#define LAV_E_ARG (-1)
+#define LAV_E_LAUNCH (-2)
+#define LAV_E_UNSUPPORTED (-3)
+
+extern "C" void lav_set_error(const char* fmt, ...);
+int lav_check_launch(const char* what);
+
+#define LAV_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            lav_set_error(__VA_ARGS__);        \
+            return LAV_E_ARG;                  \
+        }                                      \
+    } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, NaN preserved
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+}
+
+// exact (erf) GELU and its derivative -- torch.nn.GELU() default / HF "gelu"
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// counter-based dropout: keep(idx) is a pure function of (seed, element index), so the backward
+// kernels regenerate the mask instead of storing it.
+__device__ __forceinline__ uint32_t lav_mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool lav_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
+    uint32_t h = lav_mix((uint32_t)idx * 0x9E3779B9u + seed) ^ lav_mix((uint32_t)(idx >> 32) + 0x85ebca6bu);
+    return lav_mix(h) >= thresh;                           // P(keep) = 1 - thresh / 2^32
+}
+static inline uint32_t lav_drop_thresh(float p) {
+    double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

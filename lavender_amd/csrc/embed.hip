@@ -1,0 +1,338 @@
+// Memory-bound edge kernels of the LAVENDER path: patch im2col, video-token assembly (+LN), text embedding
+// (+LN +dropout), and the row gathers that build / un-build the fusion-encoder input.  One wave per row,
+// 16-byte accesses.
+#include "common.h"
+#include "../../include/lavender_hip.h"
+
+// ---- PatchEmbed3D im2col (video_swin.py:388-405) -----------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, int B, int T, int H, int W, int frame_major,
+                                                    bf16_t* __restrict__ out) {
+    const int Hp = H >> 2, Wp = W >> 2;
+    const long total = (long)B * T * Hp * 12 * Wp;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int pw = idx % Wp; long t1 = idx / Wp;
+        int chunk = t1 % 12; t1 /= 12;
+        int ph = t1 % Hp; t1 /= Hp;
+        int t = t1 % T, b = t1 / T;
+        int c = chunk >> 2, kt = (chunk >> 1) & 1, khp = chunk & 1;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int ts = t + kt;
+        if (ts < T) {                                    // zero frame appended at the END of T (:396)
+            const long plane = frame_major ? (((long)b * T + ts) * 3 + c) : (((long)b * 3 + c) * T + ts);
+            const float* p = img + plane * H * W + (long)(4 * ph + 2 * khp) * W + 4 * pw;
+            float4 r0 = *(const float4*)p, r1 = *(const float4*)(p + W);
+            v[0] = r0.x; v[1] = r0.y; v[2] = r0.z; v[3] = r0.w; v[4] = r1.x; v[5] = r1.y; v[6] = r1.z; v[7] = r1.w;
+        }
+        const long row = (((long)b * T + t) * Hp + ph) * Wp + pw;
+        *(uint4*)(out + row * 96 + c * 32 + kt * 16 + khp * 8) = pack8(v);
+    }
+}
+
+extern "C" int lav_patch_im2col(void* stream, const float* img, int B, int T, int H, int W, int frame_major, void* out) {
+    LAV_REQUIRE(img && out && B > 0 && T > 0, "lav_patch_im2col: bad arguments");
+    LAV_REQUIRE(H % 4 == 0 && W % 4 == 0, "lav_patch_im2col: H,W must be multiples of the 4x4 patch (got %d,%d)", H, W);
+    long total = (long)B * T * (H / 4) * 12 * (W / 4);
+    int grid = (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, B, T, H, W, frame_major, (bf16_t*)out);
+    return lav_check_launch("lav_patch_im2col");
+}
+
+// ---- video token assembly + LayerNorm (model.py:69-85) -----------------------------------------------
+// MAXC = chunks (of 8) per lane: Hd <= 64*8*MAXC
+template <int MAXC>
+__global__ __launch_bounds__(256) void video_embed_fwd_kernel(int B, int T, int hw, int Hd, const bf16_t* __restrict__ feat,
+                                                             const float* cls, const float* pos, const float* len,
+                                                             const float* gamma, const float* beta, float eps,
+                                                             bf16_t* __restrict__ out, long seq_rows, float* mean_o, float* rstd_o) {
+    const int lane = threadIdx.x & 63;
+    const int P = 1 + hw;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long)B * T * P) return;
+    const int pp = r % P; const int bt = r / P; const int t = bt % T, b = bt / T;
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXC; ++it) {
+        const int col = (it * 64 + lane) * 8;
+        if (col < Hd) {
+            float x[8];
+            if (pp == 0) { for (int k = 0; k < 8; ++k) x[k] = cls[col + k]; }
+            else { uint4 u = *(const uint4*)(feat + ((long)bt * hw + pp - 1) * Hd + col); unpack8(u, x); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[it][k] = x[k] + pos[(long)pp * Hd + col + k] + len[(long)t * Hd + col + k]; s += v[it][k]; }
+        }
+    }
+    const float mean = wave_sum(s) / Hd;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXC; ++it) {
+        const int col = (it * 64 + lane) * 8;
+        if (col < Hd) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { float d = v[it][k] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / Hd + eps);
+    bf16_t* o = out + ((long)b * seq_rows + (long)t * P + pp) * Hd;
+#pragma unroll
+    for (int it = 0; it < MAXC; ++it) {
+        const int col = (it * 64 + lane) * 8;
+        if (col < Hd) {
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = (v[it][k] - mean) * rstd * gamma[col + k] + beta[col + k];
+            *(uint4*)(o + col) = pack8(y);
+        }
+    }
+    if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+}
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void video_embed_bwd_kernel(int B, int T, int hw, int Hd, const bf16_t* __restrict__ dout, long seq_rows,
+                                                             const bf16_t* __restrict__ feat, const float* cls, const float* pos,
+                                                             const float* len, const float* gamma, const float* mean_i,
+                                                             const float* rstd_i, bf16_t* __restrict__ dfeat, float* d_cls, float* d_pos,
+                                                             float* d_len, float* dgamma, float* dbeta) {
+    const int lane = threadIdx.x & 63;
+    const int P = 1 + hw;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long)B * T * P) return;
+    const int pp = r % P; const int bt = r / P; const int t = bt % T, b = bt / T;
+    const float mean = mean_i[r], rstd = rstd_i[r];
+    const bf16_t* dy = dout + ((long)b * seq_rows + (long)t * P + pp) * Hd;
+    float xh[MAXC][8], gy[MAXC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXC; ++it) {
+        const int col = (it * 64 + lane) * 8;
+        if (col < Hd) {
+            float x[8], d[8];
+            if (pp == 0) { for (int k = 0; k < 8; ++k) x[k] = cls[col + k]; }
+            else { uint4 u = *(const uint4*)(feat + ((long)bt * hw + pp - 1) * Hd + col); unpack8(u, x); }
+            uint4 du = *(const uint4*)(dy + col); unpack8(du, d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xv = x[k] + pos[(long)pp * Hd + col + k] + len[(long)t * Hd + col + k];
+                xh[it][k] = (xv - mean) * rstd;
+                gy[it][k] = gamma[col + k] * d[k];
+                s1 += gy[it][k]; s2 += gy[it][k] * xh[it][k];
+                atomicAdd(dgamma + col + k, d[k] * xh[it][k]);
+                atomicAdd(dbeta + col + k, d[k]);
+            }
+        }
+    }
+    const float m1 = wave_sum(s1) / Hd, m2 = wave_sum(s2) / Hd;
+#pragma unroll
+    for (int it = 0; it < MAXC; ++it) {
+        const int col = (it * 64 + lane) * 8;
+        if (col < Hd) {
+            float dx[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                dx[k] = rstd * (gy[it][k] - m1 - xh[it][k] * m2);
+                atomicAdd(d_pos + (long)pp * Hd + col + k, dx[k]);
+                atomicAdd(d_len + (long)t * Hd + col + k, dx[k]);
+                if (pp == 0) atomicAdd(d_cls + col + k, dx[k]);
+            }
+            if (pp > 0) *(uint4*)(dfeat + ((long)bt * hw + pp - 1) * Hd + col) = pack8(dx);
+        }
+    }
+}
+
+extern "C" int lav_video_embed_fwd(void* stream, int B, int T, int hw, int Hd, const void* feat, const float* emb_cls,
+                                   const float* emb_pos, const float* emb_len, const float* gamma, const float* beta,
+                                   float eps, void* out, long seq_rows, float* mean, float* rstd) {
+    LAV_REQUIRE(B > 0 && T > 0 && hw > 0 && Hd % 8 == 0 && Hd <= 1024, "lav_video_embed_fwd: bad shape (Hd=%d)", Hd);
+    LAV_REQUIRE(feat && emb_cls && emb_pos && emb_len && gamma && beta && out && mean && rstd, "lav_video_embed_fwd: null pointer");
+    long rows = (long)B * T * (1 + hw);
+    hipLaunchKernelGGL(video_embed_fwd_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, B, T, hw, Hd,
+                       (const bf16_t*)feat, emb_cls, emb_pos, emb_len, gamma, beta, eps, (bf16_t*)out, seq_rows, mean, rstd);
+    return lav_check_launch("lav_video_embed_fwd");
+}
+
+extern "C" int lav_video_embed_bwd(void* stream, int B, int T, int hw, int Hd, const void* dout, long seq_rows, const void* feat,
+                                   const float* emb_cls, const float* emb_pos, const float* emb_len, const float* gamma,
+                                   const float* mean, const float* rstd, void* dfeat, float* d_cls, float* d_pos, float* d_len,
+                                   float* dgamma, float* dbeta) {
+    LAV_REQUIRE(B > 0 && T > 0 && hw > 0 && Hd % 8 == 0 && Hd <= 1024, "lav_video_embed_bwd: bad shape (Hd=%d)", Hd);
+    LAV_REQUIRE(dout && feat && dfeat && d_cls && d_pos && d_len && dgamma && dbeta, "lav_video_embed_bwd: null pointer");
+    long rows = (long)B * T * (1 + hw);
+    hipLaunchKernelGGL(video_embed_bwd_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, B, T, hw, Hd,
+                       (const bf16_t*)dout, seq_rows, (const bf16_t*)feat, emb_cls, emb_pos, emb_len, gamma, mean, rstd,
+                       (bf16_t*)dfeat, d_cls, d_pos, d_len, dgamma, dbeta);
+    return lav_check_launch("lav_video_embed_bwd");
+}
+
+// ---- BERT text embedding (+LN eps, +dropout) ---------------------------------------------------------
+template <int MAXC>
+__global__ __launch_bounds__(256) void text_embed_fwd_kernel(int n, int X, int Hd, const int64_t* ids, const float* word, const float* pos,
+                                                            const float* type0, const float* gamma, const float* beta, float eps,
+                                                            float p, uint32_t seed, uint32_t thresh, bf16_t* out, float* mean_o,
+                                                            float* rstd_o) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long)n * X) return;
+    const int xp = r % X;
+    const long id = ids[r];
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXC; ++it) {
+        const int col = (it * 64 + lane) * 8;
+        if (col < Hd) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[it][k] = word[id * Hd + col + k] + pos[(long)xp * Hd + col + k] + type0[col + k]; s += v[it][k]; }
+        }
+    }
+    const float mean = wave_sum(s) / Hd;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXC; ++it) {
+        const int col = (it * 64 + lane) * 8;
+        if (col < Hd) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { float d = v[it][k] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / Hd + eps);
+    const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+#pragma unroll
+    for (int it = 0; it < MAXC; ++it) {
+        const int col = (it * 64 + lane) * 8;
+        if (col < Hd) {
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                y[k] = (v[it][k] - mean) * rstd * gamma[col + k] + beta[col + k];
+                if (p > 0.f) y[k] = lav_keep(seed, (uint64_t)r * Hd + col + k, thresh) ? y[k] * inv : 0.f;
+            }
+            *(uint4*)(out + r * Hd + col) = pack8(y);
+        }
+    }
+    if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+}
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void text_embed_bwd_kernel(int n, int X, int Hd, const int64_t* ids, const bf16_t* dout, const float* word,
+                                                            const float* pos, const float* type0, const float* gamma,
+                                                            const float* mean_i, const float* rstd_i, float p, uint32_t seed,
+                                                            uint32_t thresh, float* d_word, float* d_pos, float* d_type0,
+                                                            float* dgamma, float* dbeta) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long)n * X) return;
+    const int xp = r % X;
+    const long id = ids[r];
+    const float mean = mean_i[r], rstd = rstd_i[r];
+    const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    float xh[MAXC][8], gy[MAXC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXC; ++it) {
+        const int col = (it * 64 + lane) * 8;
+        if (col < Hd) {
+            float d[8];
+            uint4 du = *(const uint4*)(dout + r * Hd + col); unpack8(du, d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (p > 0.f) d[k] = lav_keep(seed, (uint64_t)r * Hd + col + k, thresh) ? d[k] * inv : 0.f;
+                const float xv = word[id * Hd + col + k] + pos[(long)xp * Hd + col + k] + type0[col + k];
+                xh[it][k] = (xv - mean) * rstd;
+                gy[it][k] = gamma[col + k] * d[k];
+                s1 += gy[it][k]; s2 += gy[it][k] * xh[it][k];
+                atomicAdd(dgamma + col + k, d[k] * xh[it][k]);
+                atomicAdd(dbeta + col + k, d[k]);
+            }
+        }
+    }
+    const float m1 = wave_sum(s1) / Hd, m2 = wave_sum(s2) / Hd;
+#pragma unroll
+    for (int it = 0; it < MAXC; ++it) {
+        const int col = (it * 64 + lane) * 8;
+        if (col < Hd) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float dx = rstd * (gy[it][k] - m1 - xh[it][k] * m2);
+                atomicAdd(d_word + id * Hd + col + k, dx);
+                atomicAdd(d_pos + (long)xp * Hd + col + k, dx);
+                atomicAdd(d_type0 + col + k, dx);
+            }
+        }
+    }
+}
+
+extern "C" int lav_text_embed_fwd(void* stream, int n, int X, int Hd, const int64_t* ids, const float* word, const float* pos,
+                                  const float* type0, const float* gamma, const float* beta, float eps, float dropout_p,
+                                  uint32_t seed, void* out, float* mean, float* rstd) {
+    LAV_REQUIRE(n > 0 && X > 0 && Hd % 8 == 0 && Hd <= 1024, "lav_text_embed_fwd: bad shape");
+    LAV_REQUIRE(ids && word && pos && type0 && gamma && beta && out && mean && rstd, "lav_text_embed_fwd: null pointer");
+    long rows = (long)n * X;
+    hipLaunchKernelGGL(text_embed_fwd_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, X, Hd, ids, word,
+                       pos, type0, gamma, beta, eps, dropout_p, seed, lav_drop_thresh(dropout_p), (bf16_t*)out, mean, rstd);
+    return lav_check_launch("lav_text_embed_fwd");
+}
+
+extern "C" int lav_text_embed_bwd(void* stream, int n, int X, int Hd, const int64_t* ids, const void* dout, const float* word,
+                                  const float* pos, const float* type0, const float* gamma, const float* mean, const float* rstd,
+                                  float dropout_p, uint32_t seed, float* d_word, float* d_pos, float* d_type0, float* dgamma,
+                                  float* dbeta) {
+    LAV_REQUIRE(n > 0 && X > 0 && Hd % 8 == 0 && Hd <= 1024, "lav_text_embed_bwd: bad shape");
+    LAV_REQUIRE(ids && dout && d_word && d_pos && d_type0 && dgamma && dbeta, "lav_text_embed_bwd: null pointer");
+    long rows = (long)n * X;
+    hipLaunchKernelGGL(text_embed_bwd_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, X, Hd, ids,
+                       (const bf16_t*)dout, word, pos, type0, gamma, mean, rstd, dropout_p, seed, lav_drop_thresh(dropout_p), d_word,
+                       d_pos, d_type0, dgamma, dbeta);
+    return lav_check_launch("lav_text_embed_bwd");
+}
+
+// ---- row gather / gather-sum -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(int n_rows, int C, const bf16_t* src, long lds_, const int32_t* src_row,
+                                                         bf16_t* dst, long ldd) {
+    const int cpr = C / 8;
+    const long total = (long)n_rows * cpr;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = idx % cpr; const long r = idx / cpr;
+        const int sr = src_row[r];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (sr >= 0) v = *(const uint4*)(src + (long)sr * lds_ + c * 8);
+        *(uint4*)(dst + r * ldd + c * 8) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_sum_rows_kernel(int n_out, int C, const bf16_t* src, long lds_, const int32_t* start,
+                                                             const int32_t* list, bf16_t* out, long ldo) {
+    const int cpr = C / 8;
+    const long total = (long)n_out * cpr;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = idx % cpr; const long r = idx / cpr;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = start[r]; k < start[r + 1]; ++k) {
+            float v[8];
+            uint4 u = *(const uint4*)(src + (long)list[k] * lds_ + c * 8);
+            unpack8(u, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+        *(uint4*)(out + r * ldo + c * 8) = pack8(acc);
+    }
+}
+
+extern "C" int lav_gather_rows(void* stream, int n_rows, int C, const void* src, long lds_, const int32_t* src_row, void* dst,
+                               long ldd) {
+    LAV_REQUIRE(n_rows > 0 && C > 0 && C % 8 == 0 && src && src_row && dst, "lav_gather_rows: bad arguments");
+    long total = (long)n_rows * (C / 8);
+    int grid = (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n_rows, C, (const bf16_t*)src, lds_, src_row,
+                       (bf16_t*)dst, ldd);
+    return lav_check_launch("lav_gather_rows");
+}
+
+extern "C" int lav_gather_sum_rows(void* stream, int n_out, int C, const void* src, long lds_, const int32_t* start,
+                                   const int32_t* list, void* out, long ldo) {
+    LAV_REQUIRE(n_out > 0 && C > 0 && C % 8 == 0 && src && start && list && out, "lav_gather_sum_rows: bad arguments");
+    long total = (long)n_out * (C / 8);
+    int grid = (int)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256);
+    hipLaunchKernelGGL(gather_sum_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n_out, C, (const bf16_t*)src, lds_, start,
+                       list, (bf16_t*)out, ldo);
+    return lav_check_launch("lav_gather_sum_rows");
+}

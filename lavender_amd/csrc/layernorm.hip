@@ -1,0 +1,324 @@
+// Row LayerNorm forward/backward for gfx950 (HBM-bound).  A row is owned by a sub-wave group of G lanes
+// (G = 16/32/64, chosen so G*8 >= C when possible); every lane moves 16-byte (8 x bf16) chunks and keeps
+// its slice of the row in registers, so x / dy are read exactly once.  The PatchMerging 2x2 gather
+// (video_swin.py:271-284) is an address function of the same kernel instead of a materialised concat.
+#include "common.h"
+#include "../../include/lavender_hip.h"
+
+struct LnGeom {
+    int mode, H, W, C0;
+};
+
+// pointer to 8 contiguous elements [col, col+8) of logical row `row`
+__device__ __forceinline__ long ln_src_off(const LnGeom& g, int row, int col, long ld) {
+    if (g.mode == 0) return (long)row * ld + col;
+    const int H2 = g.H >> 1, W2 = g.W >> 1;
+    int w2 = row % W2, t = row / W2;
+    int h2 = t % H2, bt = t / H2;
+    int q = col / g.C0, c = col - q * g.C0;
+    int h = 2 * h2 + (q & 1), w = 2 * w2 + (q >> 1);
+    return ((long)(bt * g.H + h) * g.W + w) * ld + c;
+}
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int G, int ITERS>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int C, const bf16_t* __restrict__ x, long ldx, LnGeom geo,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float eps, bf16_t* __restrict__ y, long ldy, float* mean_out,
+                                                    float* rstd_out) {
+    const int tid = threadIdx.x, gl = tid % G;
+    const int row = blockIdx.x * (256 / G) + tid / G;
+    if (row >= rows) return;
+    float v[ITERS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        int col = (it * G + gl) * 8;
+        if (col < C) {
+            uint4 u = *(const uint4*)(x + ln_src_off(geo, row, col, ldx));
+            unpack8(u, v[it]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[it][k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[it][k] = 0.f;
+        }
+    }
+    const float mean = group_sum<G>(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        int col = (it * G + gl) * 8;
+        if (col < C) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { float d = v[it][k] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(group_sum<G>(q) / (float)C + eps);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        int col = (it * G + gl) * 8;
+        if (col < C) {
+            float o[8];
+            float4 g0 = *(const float4*)(gamma + col), g1 = *(const float4*)(gamma + col + 4);
+            float4 b0 = *(const float4*)(beta + col), b1 = *(const float4*)(beta + col + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (v[it][k] - mean) * rstd * gg[k] + bb[k];
+            *(uint4*)(y + (long)row * ldy + col) = pack8(o);
+        }
+    }
+    if (gl == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+struct LnBwdArgs {
+    int rows, C;
+    const bf16_t* dy; long lddy;
+    const bf16_t* x; long ldx;
+    LnGeom geo;
+    const float* gamma; const float* mean; const float* rstd;
+    const bf16_t* add_in; long ldadd;
+    bf16_t* dx; long lddx;
+    float* dgamma; float* dbeta;
+    lav_ln_bwd_extra ex;
+    uint32_t thresh;
+};
+
+template <int G, int ITERS>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
+    extern __shared__ float red[];                          // [256/G][C]
+    const int tid = threadIdx.x, gl = tid % G, grp = tid / G;
+    constexpr int RPW = 256 / G;
+    float dg[ITERS][8], db[ITERS][8], cs[ITERS][8];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { dg[it][k] = 0.f; db[it][k] = 0.f; cs[it][k] = 0.f; }
+    const float inv_keep = a.ex.dropout_p > 0.f ? 1.0f / (1.0f - a.ex.dropout_p) : 1.0f;
+
+    for (int row = blockIdx.x * RPW + grp; row < a.rows; row += gridDim.x * RPW) {
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        float xh[ITERS][8], gy[ITERS][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            int col = (it * G + gl) * 8;
+            if (col < a.C) {
+                float xv[8], dv[8];
+                uint4 u = *(const uint4*)(a.x + ln_src_off(a.geo, row, col, a.ldx));
+                unpack8(u, xv);
+                uint4 d = *(const uint4*)(a.dy + (long)row * a.lddy + col);
+                unpack8(d, dv);
+                float4 g0 = *(const float4*)(a.gamma + col), g1 = *(const float4*)(a.gamma + col + 4);
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    xh[it][k] = (xv[k] - mean) * rstd;
+                    gy[it][k] = gg[k] * dv[k];
+                    s1 += gy[it][k];
+                    s2 += gy[it][k] * xh[it][k];
+                    dg[it][k] += dv[k] * xh[it][k];
+                    db[it][k] += dv[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { xh[it][k] = 0.f; gy[it][k] = 0.f; }
+            }
+        }
+        const float m1 = group_sum<G>(s1) / (float)a.C, m2 = group_sum<G>(s2) / (float)a.C;
+        const float rs = a.ex.row_scale ? a.ex.row_scale[row / a.ex.rows_per_group] : 1.0f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            int col = (it * G + gl) * 8;
+            if (col < a.C) {
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = rstd * (gy[it][k] - m1 - xh[it][k] * m2);
+                const long doff = ln_src_off(a.geo, row, col, a.lddx);
+                if (a.add_in) {
+                    float r[8];
+                    uint4 u = *(const uint4*)(a.add_in + ln_src_off(a.geo, row, col, a.ldadd));
+                    unpack8(u, r);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] += r[k];
+                }
+                *(uint4*)(a.dx + doff) = pack8(o);
+                if (a.ex.dx2 || a.ex.colsum) {
+                    float o2[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float t = o[k] * rs;
+                        if (a.ex.dropout_p > 0.f)
+                            t = lav_keep(a.ex.seed, (uint64_t)row * (uint64_t)a.C + (uint64_t)(col + k), a.thresh) ? t * inv_keep : 0.f;
+                        o2[k] = t;
+                        cs[it][k] += t;
+                    }
+                    if (a.ex.dx2) *(uint4*)((bf16_t*)a.ex.dx2 + (long)row * a.ex.lddx2 + col) = pack8(o2);
+                }
+            }
+        }
+    }
+    // ---- cross-group reduction of the column accumulators, then one atomic per column per block ----
+    float* outs[3] = {a.dgamma, a.dbeta, a.ex.colsum};
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        if (!outs[w]) continue;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            int col = (it * G + gl) * 8;
+            if (col < a.C) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) red[grp * a.C + col + k] = w == 0 ? dg[it][k] : (w == 1 ? db[it][k] : cs[it][k]);
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < a.C; c += 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) s += red[r * a.C + c];
+            atomicAdd(outs[w] + c, s);
+        }
+    }
+}
+
+static inline void pick_geom(int C, int& G, int& iters) {
+    G = C <= 128 ? 16 : (C <= 256 ? 32 : 64);
+    iters = (C + G * 8 - 1) / (G * 8);
+}
+
+#define LN_DISPATCH(KERNEL, ...)                                                         \
+    if (G == 16) { KERNEL(16, 1) }                                                       \
+    else if (G == 32) { KERNEL(32, 1) }                                                  \
+    else if (iters == 1) { KERNEL(64, 1) }                                               \
+    else if (iters == 2) { KERNEL(64, 2) }                                               \
+    else if (iters == 3) { KERNEL(64, 3) }                                               \
+    else if (iters == 4) { KERNEL(64, 4) }                                               \
+    else if (iters <= 6) { KERNEL(64, 6) }                                               \
+    else { lav_set_error("layernorm: C=%d too wide (max 3072)", C); return LAV_E_UNSUPPORTED; }
+
+static int check_gather(const lav_ln_gather* g, int C, LnGeom& geo) {
+    geo.mode = 0; geo.H = geo.W = geo.C0 = 0;
+    if (g && g->mode == 1) {
+        LAV_REQUIRE(g->H % 2 == 0 && g->W % 2 == 0, "layernorm: patch-merge gather needs even H,W (got %d,%d)", g->H, g->W);
+        LAV_REQUIRE(g->C0 * 4 == C && g->C0 % 8 == 0, "layernorm: patch-merge gather needs C == 4*C0, C0 %% 8 == 0");
+        geo.mode = 1; geo.H = g->H; geo.W = g->W; geo.C0 = g->C0;
+    }
+    return LAV_OK;
+}
+
+extern "C" int lav_layernorm_fwd(void* stream, int rows, int C, const void* x, long ldx, const lav_ln_gather* gather,
+                                 const float* gamma, const float* beta, float eps, void* y, long ldy, float* mean,
+                                 float* rstd) {
+    LAV_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "lav_layernorm_fwd: rows=%d C=%d (C must be a multiple of 8)", rows, C);
+    LAV_REQUIRE(x && y && gamma && beta, "lav_layernorm_fwd: null pointer");
+    LAV_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "lav_layernorm_fwd: ld must be a multiple of 8");
+    LnGeom geo;
+    if (int rc = check_gather(gather, C, geo)) return rc;
+    int G, iters;
+    pick_geom(C, G, iters);
+    hipStream_t s = (hipStream_t)stream;
+#define K_(G_, I_)                                                                                              \
+    hipLaunchKernelGGL((ln_fwd_kernel<G_, I_>), dim3((rows + 256 / G_ - 1) / (256 / G_)), dim3(256), 0, s, rows, C, \
+                       (const bf16_t*)x, ldx, geo, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd);
+    LN_DISPATCH(K_)
+#undef K_
+    return lav_check_launch("lav_layernorm_fwd");
+}
+
+extern "C" int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, long lddy, const void* x, long ldx,
+                                 const lav_ln_gather* gather, const float* gamma, const float* mean, const float* rstd,
+                                 const void* add_in, long ldadd, void* dx, long lddx, float* dgamma, float* dbeta,
+                                 const lav_ln_bwd_extra* extra) {
+    LAV_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "lav_layernorm_bwd: rows=%d C=%d", rows, C);
+    LAV_REQUIRE(dy && x && gamma && mean && rstd && dx, "lav_layernorm_bwd: null pointer");
+    LnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    if (int rc = check_gather(gather, C, a.geo)) return rc;
+    a.rows = rows; a.C = C; a.dy = (const bf16_t*)dy; a.lddy = lddy; a.x = (const bf16_t*)x; a.ldx = ldx;
+    a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.add_in = (const bf16_t*)add_in; a.ldadd = ldadd;
+    a.dx = (bf16_t*)dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta;
+    if (extra) a.ex = *extra;
+    LAV_REQUIRE(!(a.ex.dx2 && a.geo.mode == 1), "lav_layernorm_bwd: extra output unsupported with gather");
+    a.thresh = lav_drop_thresh(a.ex.dropout_p);
+    int G, iters;
+    pick_geom(C, G, iters);
+    int rpw = 256 / G;
+    int grid = (rows + rpw - 1) / rpw;
+    if (grid > 2048) grid = 2048;
+    size_t lds = (size_t)rpw * C * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define K_(G_, I_) hipLaunchKernelGGL((ln_bwd_kernel<G_, I_>), dim3(grid), dim3(256), lds, s, a);
+    LN_DISPATCH(K_)
+#undef K_
+    return lav_check_launch("lav_layernorm_bwd");
+}
+
+// ---- out = row_scale * dropout(in), with column sums --------------------------------------------------
+__global__ __launch_bounds__(256) void scale_mask_kernel(int rows, int C, const bf16_t* in, long ldi, bf16_t* out, long ldo,
+                                                        const float* row_scale, int rpg, float p, uint32_t seed,
+                                                        uint32_t thresh, float* colsum, const bf16_t* gelu_in, long ldg) {
+    // thread owns one 8-wide column chunk; block walks rows with stride gridDim.y
+    const int chunk = blockIdx.x * 256 + threadIdx.x;
+    const int col = chunk * 8;
+    if (col >= C) return;
+    const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        float v[8];
+        uint4 u = *(const uint4*)(in + (long)row * ldi + col);
+        unpack8(u, v);
+        const float rs = row_scale ? row_scale[row / rpg] : 1.f;
+        float gg[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        if (gelu_in) {
+            float h[8];
+            uint4 hu = *(const uint4*)(gelu_in + (long)row * ldg + col);
+            unpack8(hu, h);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gg[k] = gelu_grad_f(h[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t = v[k] * rs * gg[k];
+            if (p > 0.f) t = lav_keep(seed, (uint64_t)row * (uint64_t)C + (uint64_t)(col + k), thresh) ? t * inv : 0.f;
+            v[k] = t;
+            cs[k] += t;
+        }
+        if (out) *(uint4*)(out + (long)row * ldo + col) = pack8(v);
+    }
+    if (colsum) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (col + k < C) atomicAdd(colsum + col + k, cs[k]);
+    }
+}
+
+extern "C" int lav_scale_mask_rows(void* stream, int rows, int C, const void* in, long ldi, void* out, long ldo,
+                                   const float* row_scale, int rows_per_group, float dropout_p, uint32_t seed,
+                                   float* colsum, const void* gelu_in, long ldg) {
+    LAV_REQUIRE(rows > 0 && C > 0 && in, "lav_scale_mask_rows: bad arguments rows=%d C=%d", rows, C);
+    LAV_REQUIRE(!out || C % 8 == 0, "lav_scale_mask_rows: C must be a multiple of 8 when an output is written");
+    int chunks = (C + 7) / 8;
+    int gy = rows < 512 ? rows : 512;
+    hipLaunchKernelGGL(scale_mask_kernel, dim3((chunks + 255) / 256, gy), dim3(256), 0, (hipStream_t)stream, rows, C,
+                       (const bf16_t*)in, ldi, (bf16_t*)out, ldo, row_scale, rows_per_group > 0 ? rows_per_group : 1,
+                       dropout_p, seed, lav_drop_thresh(dropout_p), colsum, (const bf16_t*)gelu_in, ldg);
+    return lav_check_launch("lav_scale_mask_rows");
+}
+
+extern "C" int lav_colsum_bf16(void* stream, int rows, int C, const void* x, long ldx, float* out) {
+    // C may have a ragged tail (vocab 30522): rows are read in whole 16-byte chunks (ldx >= round_up(C, 8)),
+    // only columns < C are accumulated
+    LAV_REQUIRE(rows > 0 && C > 0 && x && out, "lav_colsum_bf16: bad arguments");
+    return lav_scale_mask_rows(stream, rows, C, x, ldx, nullptr, 0, nullptr, 1, 0.f, 0, out, nullptr, 0);
+}

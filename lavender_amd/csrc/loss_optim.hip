@@ -1,0 +1,211 @@
+// Cross-entropy (fused forward + in-place logit gradient) and the flat-arena optimizer kernels.  All HBM-bound.
+#include "common.h"
+#include "../../include/lavender_hip.h"
+
+// ---- cross entropy, ignore_index = -1 (agent.py:72; main_pretrain_mlm.py:158-163) ---------------------
+// one 256-thread block per row; online (max, sum-exp) in a single read, then one write pass
+__global__ __launch_bounds__(256) void ce_kernel(int rows, int V, bf16_t* logits, long ld, const int64_t* labels, float* loss_sum,
+                                                float grad_scale, int write_grad) {
+    __shared__ float sm[8], ss[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bf16_t* x = logits + (long)row * ld;
+    const long label = labels[row];
+    const int nchunk = (int)(ld / 8);
+    if (label < 0) {                                       // unlabelled row: zero gradient, no loss
+        if (write_grad)
+            for (int c = tid; c < nchunk; c += 256) *(uint4*)(x + c * 8) = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    float m = -INFINITY, s = 0.f;
+    for (int c = tid; c < nchunk; c += 256) {
+        float v[8];
+        uint4 u = *(const uint4*)(x + c * 8);
+        unpack8(u, v);
+        float cm = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (c * 8 + k >= V) v[k] = -INFINITY; cm = fmaxf(cm, v[k]); }
+        if (cm > m) { s *= __expf(m - cm); m = cm; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += __expf(v[k] - m);
+    }
+    // wave then block reduction of (m, s)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        const float mn = fmaxf(m, m2);
+        s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mn));
+        m = mn;
+    }
+    if (lane == 0) { sm[wave] = m; ss[wave] = s; }
+    __syncthreads();
+    float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float S = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) S += ss[w] * __expf(sm[w] - M);
+    const float lse = M + __logf(S);
+    if (tid == 0) {
+        atomicAdd(loss_sum, lse - bf2f(x[label]));
+        atomicAdd(loss_sum + 1, 1.0f);
+    }
+    if (!write_grad) return;
+    __syncthreads();                                       // x[label] read before anybody overwrites it
+    for (int c = tid; c < nchunk; c += 256) {
+        float v[8];
+        uint4 u = *(const uint4*)(x + c * 8);
+        unpack8(u, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int col = c * 8 + k;
+            float g = col < V ? __expf(v[k] - lse) : 0.f;
+            if (col == label) g -= 1.f;
+            v[k] = g * grad_scale;
+        }
+        *(uint4*)(x + c * 8) = pack8(v);
+    }
+}
+
+extern "C" int lav_cross_entropy_fwd_bwd(void* stream, int rows, int V, void* logits, long ld, const int64_t* labels, float* loss_sum,
+                                         float grad_scale, int write_grad) {
+    LAV_REQUIRE(rows > 0 && V > 0 && logits && labels && loss_sum, "lav_cross_entropy_fwd_bwd: bad arguments");
+    LAV_REQUIRE(ld % 8 == 0 && ld >= V, "lav_cross_entropy_fwd_bwd: ld must be a multiple of 8 and >= V");
+    hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, rows, V, (bf16_t*)logits, ld, labels, loss_sum, grad_scale, write_grad);
+    return lav_check_launch("lav_cross_entropy_fwd_bwd");
+}
+
+__global__ __launch_bounds__(256) void scale_bf16_kernel(long n8, bf16_t* x, const float* cnt, float gscale) {
+    const float s = cnt ? gscale / fmaxf(cnt[1], 1.f) : gscale;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8];
+        uint4 u = *(uint4*)(x + i * 8);
+        unpack8(u, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= s;
+        *(uint4*)(x + i * 8) = pack8(v);
+    }
+}
+
+extern "C" int lav_scale_by_count(void* stream, long n_elems, void* x_bf16, const float* loss_sum, float gscale) {
+    LAV_REQUIRE(n_elems > 0 && n_elems % 8 == 0 && x_bf16, "lav_scale_by_count: bad arguments");
+    long n8 = n_elems / 8;
+    int grid = (int)((n8 + 255) / 256 > 8192 ? 8192 : (n8 + 255) / 256);
+    hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n8, (bf16_t*)x_bf16, loss_sum, gscale);
+    return lav_check_launch("lav_scale_by_count");
+}
+
+// ---- optimizer over the flat arena ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* g, float* out) {
+    float s = 0.f;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = ((const float4*)g)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long i = n4 * 4; i < n; ++i) s += g[i] * g[i];
+    s = wave_sum(s);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+extern "C" int lav_sumsq_f32(void* stream, long n, const float* g, float* out) {
+    LAV_REQUIRE(n > 0 && g && out && ((uintptr_t)g % 16) == 0, "lav_sumsq_f32: bad arguments");
+    int grid = (int)((n / 4 + 255) / 256 > 2048 ? 2048 : (n / 4 + 255) / 256);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, g, out);
+    return lav_check_launch("lav_sumsq_f32");
+}
+
+struct AdamArgs {
+    long n; float* p; const float* g; float* m; float* v; bf16_t* pb;
+    const uint8_t* grp;
+    float lr[4], wd[4];
+    float b1, b2, eps, bc1, bc2, max_norm, grad_div;
+    const float* gradsq;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+    float coef = 1.f / a.grad_div;
+    if (a.gradsq && a.max_norm > 0.f) {
+        // clip_grad_norm_ (agent.py:246): total norm of the (already averaged) gradient
+        const float tn = sqrtf(a.gradsq[0]) / a.grad_div;
+        const float c = a.max_norm / (tn + 1e-6f);
+        if (c < 1.f) coef *= c;
+    }
+    const long n4 = a.n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 p = ((float4*)a.p)[i], g = ((const float4*)a.g)[i], m = ((float4*)a.m)[i], v = ((float4*)a.v)[i];
+        float pp[4] = {p.x, p.y, p.z, p.w}, gg[4] = {g.x, g.y, g.z, g.w}, mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
+        const int gi = a.grp ? a.grp[i >> 4] & 3 : 0;
+        const float lr = a.lr[gi], wd = a.wd[gi];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * coef;
+            pp[k] *= 1.f - lr * wd;
+            mm[k] = a.b1 * mm[k] + (1.f - a.b1) * gk;
+            vv[k] = a.b2 * vv[k] + (1.f - a.b2) * gk * gk;
+            const float denom = sqrtf(vv[k]) / sqrtf(a.bc2) + a.eps;
+            pp[k] -= (lr / a.bc1) * mm[k] / denom;
+        }
+        ((float4*)a.p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        ((float4*)a.m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        ((float4*)a.v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (a.pb) {
+            uint2 w; w.x = pack2(pp[0], pp[1]); w.y = pack2(pp[2], pp[3]);
+            ((uint2*)a.pb)[i] = w;
+        }
+    }
+}
+
+extern "C" int lav_adamw_step(void* stream, long n, float* p, const float* g, float* m, float* v, void* p_bf16,
+                              const uint8_t* block_group, const float lr[4], const float wd[4], float beta1, float beta2,
+                              float eps, int step, const float* gradsq, float max_norm, float grad_div) {
+    LAV_REQUIRE(n > 0 && n % 64 == 0 && p && g && m && v && lr && wd, "lav_adamw_step: n must be a positive multiple of 64 (arena blocks)");
+    LAV_REQUIRE(step >= 1, "lav_adamw_step: step counts from 1");
+    AdamArgs a;
+    a.n = n; a.p = p; a.g = g; a.m = m; a.v = v; a.pb = (bf16_t*)p_bf16;
+    a.grp = block_group;
+    for (int k = 0; k < 4; ++k) { a.lr[k] = lr[k]; a.wd[k] = wd[k]; }
+    a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+    a.bc1 = 1.f - powf(beta1, (float)step); a.bc2 = 1.f - powf(beta2, (float)step);
+    a.max_norm = max_norm; a.grad_div = grad_div > 0.f ? grad_div : 1.f; a.gradsq = gradsq;
+    int grid = (int)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return lav_check_launch("lav_adamw_step");
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(long n, const float* in, bf16_t* out) {
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = ((const float4*)in)[i];
+        uint2 w; w.x = pack2(v.x, v.y); w.y = pack2(v.z, v.w);
+        ((uint2*)out)[i] = w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long i = n4 * 4; i < n; ++i) out[i] = f2bf(in[i]);
+}
+
+extern "C" int lav_cast_f32_to_bf16(void* stream, long n, const float* in, void* out) {
+    LAV_REQUIRE(n > 0 && in && out, "lav_cast_f32_to_bf16: bad arguments");
+    int grid = (int)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, in, (bf16_t*)out);
+    return lav_check_launch("lav_cast_f32_to_bf16");
+}
+
+// per-sample stochastic depth factors (video_swin.py:46-54): scale = floor(keep + u) / keep
+__global__ void droppath_kernel(int n_blocks, int B, const float* keep_prob, uint32_t seed, float* scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_blocks * B) return;
+    const float keep = keep_prob[i / B];
+    const float u = (float)(lav_mix(lav_mix((uint32_t)i * 0x9E3779B9u + seed)) >> 8) * (1.0f / 16777216.0f);
+    scale[i] = keep >= 1.f ? 1.f : floorf(keep + u) / keep;
+}
+
+extern "C" int lav_fill_droppath(void* stream, int n_blocks, int B, const float* keep_prob, uint32_t seed, float* scale) {
+    LAV_REQUIRE(n_blocks > 0 && B > 0 && keep_prob && scale, "lav_fill_droppath: bad arguments");
+    int n = n_blocks * B;
+    hipLaunchKernelGGL(droppath_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_blocks, B, keep_prob, seed, scale);
+    return lav_check_launch("lav_fill_droppath");
+}

@@ -1,0 +1,451 @@
+"""Forward/backward orchestration of the hot path on top of the HIP kernels (lavender_amd.hip).
+
+Each torch.autograd.Function below is one *stage* of the reference model (a Swin block, a patch merge, a BERT
+layer, ...): its forward enqueues the stage's kernels and keeps the activations the backward needs; its backward
+enqueues the hand-written backward kernels, ACCUMULATES parameter gradients straight into the flat gradient
+arena (fp32 atomics) and returns only the activation gradient.  torch.autograd is used for the stage-level graph
+bookkeeping only -- no arithmetic runs in ATen.
+
+`anchor` is a 1-element requires-grad tensor (arena.anchor) threaded through every stage so that autograd runs
+the stage's backward even though its parameters are not autograd inputs.
+"""
+import numpy as np
+import torch
+
+from . import hip as K
+
+bf16 = torch.bfloat16
+
+
+def W16(p):
+    try:
+        return p._lav16
+    except AttributeError:
+        raise RuntimeError("parameter is not in a ParamArena: call model.cuda() / model.build_arena() first") from None
+
+
+def G(p):
+    return p._lavg
+
+
+def _keep(ctx):
+    """True when this stage will be differentiated (autograd Function.forward itself runs in no-grad mode, so
+    the decision comes from the inputs' needs_input_grad -- the arena anchor requires grad iff grad mode was on)."""
+    return any(ctx.needs_input_grad)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Swin stages
+# ---------------------------------------------------------------------------------------------------
+class PatchEmbedFn(torch.autograd.Function):
+    """PatchEmbed3D.forward (video_swin.py:388-405): im2col + GEMM + LayerNorm -> channels-last tokens."""
+
+    @staticmethod
+    def forward(ctx, anchor, img, mod, frame_major):
+        B, T = (img.shape[0], img.shape[1]) if frame_major else (img.shape[0], img.shape[2])
+        H, W = img.shape[-2], img.shape[-1]
+        E = mod.embed_dim
+        img = img.contiguous().float()
+        cols = K.patch_im2col(img, B, T, H, W, frame_major)
+        M = cols.shape[0]
+        w16 = W16(mod.proj.weight).view(E, 96)
+        y = K.gemm(0, cols, w16, M, E, 96, bias=mod.proj.bias.data)
+        x, mean, rstd = K.layernorm_fwd(y, M, E, mod.norm.weight.data, mod.norm.bias.data, 1e-5, want_stats=_keep(ctx))
+        ctx.mod = mod
+        ctx.save_for_backward(cols, y, mean, rstd)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        mod = ctx.mod
+        cols, y, mean, rstd = ctx.saved_tensors
+        M, E = y.shape
+        dx = dx.contiguous()
+        dy = K.layernorm_bwd(dx, y, M, E, mod.norm.weight.data, mean, rstd, G(mod.norm.weight), G(mod.norm.bias),
+                             colsum=G(mod.proj.bias))
+        K.gemm(2, dy, cols, E, 96, M, out=G(mod.proj.weight).view(E, 96), accumulate=True, splits=K.splits_for(E, 96, M))
+        return None, None, None, None
+
+
+class SwinBlockFn(torch.autograd.Function):
+    """SwinTransformerBlock3D.forward (video_swin.py:204-261) on (M, C) channels-last tokens."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, blk, geo, dp_attn, dp_mlp):
+        M, C = x.shape
+        heads = blk.num_heads
+        B, D, H, Wd = geo["B"], geo["D"], geo["H"], geo["W"]
+        rpg = M // B
+        a, mlp = blk.attn, blk.mlp
+        keep = _keep(ctx)
+        y1, mean1, rstd1 = K.layernorm_fwd(x, M, C, blk.norm1.weight.data, blk.norm1.bias.data, 1e-5, want_stats=keep)
+        qkv = K.gemm(0, y1, W16(a.qkv.weight), M, 3 * C, C, bias=a.qkv.bias.data)
+        win, sh, cfg = geo["window"], geo["shift"], geo["cfg_window"]
+        att = K.Attn(0, heads, C // heads, B=B, D=D, H=H, W=Wd, wd=win[0], wh=win[1], ww=win[2], sd=sh[0], sh=sh[1],
+                     sw=sh[2], cfg_wd=cfg[0], cfg_wh=cfg[1], cfg_ww=cfg[2], bias_table=a.relative_position_bias_table.data)
+        lse = torch.empty(att.lse_elems(), dtype=torch.float32, device=x.device) if keep else None
+        ao = torch.empty((M, C), dtype=bf16, device=x.device)
+        att.fwd(qkv, ao, lse)
+        x_mid = K.gemm(0, ao, W16(a.proj.weight), M, C, C, bias=a.proj.bias.data, row_scale=dp_attn, rows_per_group=rpg,
+                       residual=x)
+        y2, mean2, rstd2 = K.layernorm_fwd(x_mid, M, C, blk.norm2.weight.data, blk.norm2.bias.data, 1e-5, want_stats=keep)
+        h_pre = torch.empty((M, 4 * C), dtype=bf16, device=x.device) if keep else None
+        h = K.gemm(0, y2, W16(mlp.fc1.weight), M, 4 * C, C, bias=mlp.fc1.bias.data, act=1, preact=h_pre)
+        out = K.gemm(0, h, W16(mlp.fc2.weight), M, C, 4 * C, bias=mlp.fc2.bias.data, row_scale=dp_mlp, rows_per_group=rpg,
+                     residual=x_mid)
+        if keep:
+            ctx.blk, ctx.att, ctx.rpg = blk, att, rpg
+            ctx.keep_attn = float(blk.keep_prob) if dp_attn is not None else 1.0
+            ctx.has_dp = dp_attn is not None
+            ctx.save_for_backward(x, y1, mean1, rstd1, qkv, ao, lse, x_mid, y2, mean2, rstd2, h_pre, h,
+                                  dp_attn if dp_attn is not None else x.new_empty(0),
+                                  dp_mlp if dp_mlp is not None else x.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        blk, att, rpg = ctx.blk, ctx.att, ctx.rpg
+        a, mlp = blk.attn, blk.mlp
+        x, y1, mean1, rstd1, qkv, ao, lse, x_mid, y2, mean2, rstd2, h_pre, h, dp_attn, dp_mlp = ctx.saved_tensors
+        if not ctx.has_dp:
+            dp_attn = dp_mlp = None
+        alpha = 1.0 / ctx.keep_attn
+        M, C = x.shape
+        dy = dy.contiguous()
+        # --- MLP branch: out = x_mid + s * fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------
+        K.scale_mask_rows(dy, M, C, row_scale=dp_mlp, rows_per_group=rpg, colsum=G(mlp.fc2.bias))
+        K.gemm(2, dy, h, C, 4 * C, M, out=G(mlp.fc2.weight), accumulate=True, k_keep=dp_mlp, k_rows_per_group=rpg,
+               alpha=alpha if dp_mlp is not None else 1.0, splits=K.splits_for(C, 4 * C, M))
+        dh = K.gemm(1, dy, W16(mlp.fc2.weight), M, 4 * C, C, gelu_in=h_pre, row_scale=dp_mlp, rows_per_group=rpg,
+                    colsum=G(mlp.fc1.bias))
+        K.gemm(2, dh, y2, 4 * C, C, M, out=G(mlp.fc1.weight), accumulate=True, splits=K.splits_for(4 * C, C, M))
+        d_y2 = K.gemm(1, dh, W16(mlp.fc1.weight), M, C, 4 * C)
+        del dh
+        d_mid = K.layernorm_bwd(d_y2, x_mid, M, C, blk.norm2.weight.data, mean2, rstd2, G(blk.norm2.weight), G(blk.norm2.bias),
+                                add_in=dy)
+        # --- attention branch: x_mid = x + s * proj(attn(qkv(LN1(x)))) ---------------------------------
+        K.scale_mask_rows(d_mid, M, C, row_scale=dp_attn, rows_per_group=rpg, colsum=G(a.proj.bias))
+        K.gemm(2, d_mid, ao, C, C, M, out=G(a.proj.weight), accumulate=True, k_keep=dp_attn, k_rows_per_group=rpg,
+               alpha=alpha if dp_attn is not None else 1.0, splits=K.splits_for(C, C, M))
+        d_ao = K.gemm(1, d_mid, W16(a.proj.weight), M, C, C, row_scale=dp_attn, rows_per_group=rpg)
+        dqkv = torch.empty_like(qkv)
+        att.bwd(qkv, ao, d_ao, lse, dqkv, G(a.relative_position_bias_table))
+        K.colsum(dqkv, M, 3 * C, G(a.qkv.bias))
+        K.gemm(2, dqkv, y1, 3 * C, C, M, out=G(a.qkv.weight), accumulate=True, splits=K.splits_for(3 * C, C, M))
+        d_y1 = K.gemm(1, dqkv, W16(a.qkv.weight), M, C, 3 * C)
+        dx = K.layernorm_bwd(d_y1, x, M, C, blk.norm1.weight.data, mean1, rstd1, G(blk.norm1.weight), G(blk.norm1.bias),
+                             add_in=d_mid)
+        return None, dx, None, None, None, None
+
+
+class PatchMergeFn(torch.autograd.Function):
+    """PatchMerging.forward (video_swin.py:271-287): 2x2 gather + LN(4C) + Linear(4C -> 2C, no bias)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, mod, BT, H, W):
+        M, C = x.shape
+        assert H % 2 == 0 and W % 2 == 0, "PatchMerging with odd H/W (pad branch video_swin.py:274-276) is not supported"
+        rows = M // 4
+        y, mean, rstd = K.layernorm_fwd(x, rows, 4 * C, mod.norm.weight.data, mod.norm.bias.data, 1e-5, gather=(H, W, C),
+                                        want_stats=_keep(ctx))
+        out = K.gemm(0, y, W16(mod.reduction.weight), rows, 2 * C, 4 * C)
+        ctx.mod, ctx.geo = mod, (H, W, C)
+        ctx.save_for_backward(x, y, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod = ctx.mod
+        H, W, C = ctx.geo
+        x, y, mean, rstd = ctx.saved_tensors
+        rows = y.shape[0]
+        dout = dout.contiguous()
+        K.gemm(2, dout, y, 2 * C, 4 * C, rows, out=G(mod.reduction.weight), accumulate=True, splits=K.splits_for(2 * C, 4 * C, rows))
+        d_y = K.gemm(1, dout, W16(mod.reduction.weight), rows, 4 * C, 2 * C)
+        dx = K.layernorm_bwd(d_y, x, rows, 4 * C, mod.norm.weight.data, mean, rstd, G(mod.norm.weight), G(mod.norm.bias),
+                             gather=(H, W, C))
+        return None, dx, None, None, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """Plain LayerNorm stage (SwinTransformer3D.norm, video_swin.py:476-478)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, mod, eps):
+        M, C = x.shape
+        y, mean, rstd = K.layernorm_fwd(x, M, C, mod.weight.data, mod.bias.data, eps, want_stats=_keep(ctx))
+        ctx.mod = mod
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        mod = ctx.mod
+        x, mean, rstd = ctx.saved_tensors
+        M, C = x.shape
+        dx = K.layernorm_bwd(dy.contiguous(), x, M, C, mod.weight.data, mean, rstd, G(mod.weight), G(mod.bias))
+        return None, dx, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# EncVideo tail / EncTxt
+# ---------------------------------------------------------------------------------------------------
+class VideoEmbedFn(torch.autograd.Function):
+    """EncVideo.forward after the backbone (model.py:48-91): fc, cls/pos/len, LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, anchor, tok, enc, B, T, hw):
+        M, Cl = tok.shape
+        Hd = enc.img_feature_dim
+        if enc.fc is not None:
+            feat = K.gemm(0, tok, W16(enc.fc.weight), M, Hd, Cl, bias=enc.fc.bias.data)
+        else:
+            feat = tok
+        Lv = T * (1 + hw)
+        out = torch.empty((B, Lv, Hd), dtype=bf16, device=tok.device)
+        mean, rstd = K.video_embed_fwd(feat, B, T, hw, Hd, enc.emb_cls.data, enc.emb_pos.data, enc.emb_len.data,
+                                       enc.norm.weight.data, enc.norm.bias.data, 1e-5, out, Lv)
+        ctx.enc, ctx.dims = enc, (B, T, hw)
+        ctx.save_for_backward(tok, feat, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        enc = ctx.enc
+        B, T, hw = ctx.dims
+        tok, feat, mean, rstd = ctx.saved_tensors
+        M, Cl = tok.shape
+        Hd = enc.img_feature_dim
+        dout = dout.contiguous()
+        dfeat = torch.empty((M, Hd), dtype=bf16, device=tok.device)
+        K.video_embed_bwd(dout, T * (1 + hw), feat, B, T, hw, Hd, enc.emb_cls.data, enc.emb_pos.data, enc.emb_len.data,
+                          enc.norm.weight.data, mean, rstd, dfeat, G(enc.emb_cls), G(enc.emb_pos), G(enc.emb_len),
+                          G(enc.norm.weight), G(enc.norm.bias))
+        if enc.fc is None:
+            return None, dfeat, None, None, None, None
+        K.colsum(dfeat, M, Hd, G(enc.fc.bias))
+        K.gemm(2, dfeat, tok, Hd, Cl, M, out=G(enc.fc.weight), accumulate=True, splits=K.splits_for(Hd, Cl, M))
+        dtok = K.gemm(1, dfeat, W16(enc.fc.weight), M, Cl, Hd)
+        return None, dtok, None, None, None, None
+
+
+class TextEmbedFn(torch.autograd.Function):
+    """BertEmbeddings as used by EncTxt.forward (model.py:125-129)."""
+
+    @staticmethod
+    def forward(ctx, anchor, ids, emb, dropout_p):
+        n, X = ids.shape
+        Hd = emb.word_embeddings.weight.shape[1]
+        ids = ids.contiguous()
+        seed = K.next_seed()
+        out, mean, rstd = K.text_embed_fwd(ids, n, X, Hd, emb.word_embeddings.weight.data, emb.position_embeddings.weight.data,
+                                           emb.token_type_embeddings.weight.data, emb.LayerNorm.weight.data,
+                                           emb.LayerNorm.bias.data, emb.LayerNorm.eps, dropout_p, seed)
+        ctx.emb, ctx.p, ctx.seed = emb, dropout_p, seed
+        ctx.save_for_backward(ids, mean, rstd)
+        return out.view(n, X, Hd)
+
+    @staticmethod
+    def backward(ctx, dout):
+        emb = ctx.emb
+        ids, mean, rstd = ctx.saved_tensors
+        n, X = ids.shape
+        Hd = emb.word_embeddings.weight.shape[1]
+        K.text_embed_bwd(ids, dout.contiguous(), n, X, Hd, emb.word_embeddings.weight.data, emb.position_embeddings.weight.data,
+                         emb.token_type_embeddings.weight.data, emb.LayerNorm.weight.data, mean, rstd, ctx.p, ctx.seed,
+                         G(emb.word_embeddings.weight), G(emb.position_embeddings.weight), G(emb.token_type_embeddings.weight),
+                         G(emb.LayerNorm.weight), G(emb.LayerNorm.bias))
+        return None, None, None, None
+
+
+class PairSeqFn(torch.autograd.Function):
+    """Builds the fusion input [video rows of sample vi | text rows of sample ti] for every pair
+    (T.cat at model.py:235 + the pair list of main_pretrain_mlm.py:74-111) with one row-gather kernel;
+    the backward is one gather-sum kernel over the inverse (CSR) map."""
+
+    @staticmethod
+    def forward(ctx, f_img, f_txt, vi, ti):
+        B, Lv, Hd = f_img.shape
+        X = f_txt.shape[1]
+        n = len(vi)
+        L = Lv + X
+        dev = f_img.device
+        src = torch.cat([f_img.reshape(B * Lv, Hd), f_txt.reshape(B * X, Hd)], 0)
+        vi = np.asarray(vi, dtype=np.int64)
+        ti = np.asarray(ti, dtype=np.int64)
+        idx = np.empty((n, L), dtype=np.int32)
+        idx[:, :Lv] = vi[:, None] * Lv + np.arange(Lv)[None, :]
+        idx[:, Lv:] = B * Lv + ti[:, None] * X + np.arange(X)[None, :]
+        flat = idx.reshape(-1)
+        out = K.gather_rows(src, torch.from_numpy(flat).to(dev, non_blocking=True), n * L, Hd)
+        if _keep(ctx):
+            order = np.argsort(flat, kind="stable").astype(np.int32)
+            start = np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=B * L))]).astype(np.int32)
+            ctx.csr = (torch.from_numpy(start).to(dev, non_blocking=True), torch.from_numpy(order).to(dev, non_blocking=True))
+            ctx.meta = (B, Lv, X, Hd, n)
+        return out.view(n, L, Hd)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Lv, X, Hd, n = ctx.meta
+        start, order = ctx.csr
+        d = K.gather_sum_rows(dout.contiguous().view(n * (Lv + X), Hd), start, order, B * (Lv + X), Hd)
+        return d[:B * Lv].view(B, Lv, Hd), d[B * Lv:].view(B, X, Hd), None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# fusion encoder layer / MLM head / loss
+# ---------------------------------------------------------------------------------------------------
+class BertLayerFn(torch.autograd.Function):
+    """One post-LN BertLayer of the fusion encoder (HF BertLayer as called from model.py:242)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, layer, key_mask, n, L, p_hidden, p_attn):
+        R, Hd = x.shape
+        heads = layer.num_heads
+        arena = layer._arena()
+        att_m = layer.attention.self
+        wqkv16, _, _ = arena.fused_view(att_m.query.weight, 3 * Hd)
+        _, _, bqkv = arena.fused_view(att_m.query.bias, 3 * Hd)
+        keep = _keep(ctx)
+        qkv = K.gemm(0, x, wqkv16, R, 3 * Hd, Hd, bias=bqkv)
+        s_att, s1, s2 = K.next_seed(), K.next_seed(), K.next_seed()
+        att = K.Attn(1, heads, Hd // heads, n_seq=n, L=L, key_mask=key_mask, dropout_p=p_attn, seed=s_att)
+        lse = torch.empty(att.lse_elems(), dtype=torch.float32, device=x.device) if keep else None
+        cx = torch.empty((R, Hd), dtype=bf16, device=x.device)
+        att.fwd(qkv, cx, lse)
+        ao = layer.attention.output
+        pre1 = K.gemm(0, cx, W16(ao.dense.weight), R, Hd, Hd, bias=ao.dense.bias.data, dropout_p=p_hidden, seed=s1, residual=x)
+        x1, mean1, rstd1 = K.layernorm_fwd(pre1, R, Hd, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, ao.LayerNorm.eps,
+                                           want_stats=keep)
+        inter, outp = layer.intermediate, layer.output
+        F = inter.dense.weight.shape[0]
+        h_pre = torch.empty((R, F), dtype=bf16, device=x.device) if keep else None
+        h = K.gemm(0, x1, W16(inter.dense.weight), R, F, Hd, bias=inter.dense.bias.data, act=1, preact=h_pre)
+        pre2 = K.gemm(0, h, W16(outp.dense.weight), R, Hd, F, bias=outp.dense.bias.data, dropout_p=p_hidden, seed=s2, residual=x1)
+        y, mean2, rstd2 = K.layernorm_fwd(pre2, R, Hd, outp.LayerNorm.weight.data, outp.LayerNorm.bias.data, outp.LayerNorm.eps,
+                                          want_stats=keep)
+        if keep:
+            ctx.layer, ctx.att, ctx.seeds, ctx.p = layer, att, (s1, s2), p_hidden
+            ctx.save_for_backward(x, qkv, cx, lse, pre1, mean1, rstd1, x1, h_pre, h, pre2, mean2, rstd2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer, att, (s1, s2), p = ctx.layer, ctx.att, ctx.seeds, ctx.p
+        x, qkv, cx, lse, pre1, mean1, rstd1, x1, h_pre, h, pre2, mean2, rstd2 = ctx.saved_tensors
+        R, Hd = x.shape
+        arena = layer._arena()
+        att_m, ao, inter, outp = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+        F = inter.dense.weight.shape[0]
+        wqkv16, gwqkv, _ = arena.fused_view(att_m.query.weight, 3 * Hd)
+        _, gbqkv, _ = arena.fused_view(att_m.query.bias, 3 * Hd)
+        dy = dy.contiguous()
+        # out = LN(pre2), pre2 = x1 + dropout(dense(h))
+        d_dense2 = torch.empty((R, Hd), dtype=bf16, device=x.device)
+        d_pre2 = K.layernorm_bwd(dy, pre2, R, Hd, outp.LayerNorm.weight.data, mean2, rstd2, G(outp.LayerNorm.weight),
+                                 G(outp.LayerNorm.bias), dx2=d_dense2, dropout_p=p, seed=s2, colsum=G(outp.dense.bias))
+        K.gemm(2, d_dense2, h, Hd, F, R, out=G(outp.dense.weight), accumulate=True, splits=K.splits_for(Hd, F, R))
+        dh = K.gemm(1, d_dense2, W16(outp.dense.weight), R, F, Hd, gelu_in=h_pre, colsum=G(inter.dense.bias))
+        K.gemm(2, dh, x1, F, Hd, R, out=G(inter.dense.weight), accumulate=True, splits=K.splits_for(F, Hd, R))
+        d_x1 = K.gemm(1, dh, W16(inter.dense.weight), R, Hd, F, residual=d_pre2)
+        del dh
+        # x1 = LN(pre1), pre1 = x + dropout(dense(ctx))
+        d_dense1 = d_dense2
+        d_pre1 = K.layernorm_bwd(d_x1, pre1, R, Hd, ao.LayerNorm.weight.data, mean1, rstd1, G(ao.LayerNorm.weight),
+                                 G(ao.LayerNorm.bias), dx2=d_dense1, dropout_p=p, seed=s1, colsum=G(ao.dense.bias))
+        K.gemm(2, d_dense1, cx, Hd, Hd, R, out=G(ao.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))
+        d_cx = K.gemm(1, d_dense1, W16(ao.dense.weight), R, Hd, Hd)
+        dqkv = torch.empty_like(qkv)
+        att.bwd(qkv, cx, d_cx, lse, dqkv, None)
+        K.colsum(dqkv, R, 3 * Hd, gbqkv)
+        K.gemm(2, dqkv, x, 3 * Hd, Hd, R, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, R))
+        dx = K.gemm(1, dqkv, wqkv16, R, Hd, 3 * Hd, residual=d_pre1)
+        return None, dx, None, None, None, None, None, None
+
+
+class MLMHeadFn(torch.autograd.Function):
+    """BertOnlyMLMHead (main_pretrain_mlm.py:46-48,69,115): dense+GELU, LayerNorm, vocab projection."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, head):
+        shp = x.shape
+        Hd = shp[-1]
+        x2 = x.reshape(-1, Hd).contiguous()
+        R = x2.shape[0]
+        tr, dec = head.predictions.transform, head.predictions.decoder
+        V = dec.weight.shape[0]
+        keep = _keep(ctx)
+        t_pre = torch.empty((R, Hd), dtype=bf16, device=x.device) if keep else None
+        t = K.gemm(0, x2, W16(tr.dense.weight), R, Hd, Hd, bias=tr.dense.bias.data, act=1, preact=t_pre)
+        tn, mean, rstd = K.layernorm_fwd(t, R, Hd, tr.LayerNorm.weight.data, tr.LayerNorm.bias.data, tr.LayerNorm.eps,
+                                         want_stats=keep)
+        ld = (V + 7) // 8 * 8
+        buf = torch.empty((R, ld), dtype=bf16, device=x.device)
+        K.gemm(0, tn, W16(dec.weight), R, V, Hd, out=buf, bias=dec.bias.data)
+        ctx.head, ctx.shp = head, shp
+        ctx.save_for_backward(x2, t_pre, t, mean, rstd, tn)
+        return buf[:, :V].view(*shp[:-1], V)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        head = ctx.head
+        x2, t_pre, t, mean, rstd, tn = ctx.saved_tensors
+        R, Hd = x2.shape
+        tr, dec = head.predictions.transform, head.predictions.decoder
+        V = dec.weight.shape[0]
+        ld = (V + 7) // 8 * 8
+        d2 = dlogits.reshape(R, V) if dlogits.is_contiguous() else dlogits
+        if d2.dim() != 2:
+            d2 = d2.reshape(R, V)
+        if d2.stride(-1) != 1 or d2.stride(0) % 8 != 0:
+            pad = torch.zeros((R, ld), dtype=bf16, device=d2.device)
+            pad[:, :V].copy_(d2)
+            d2 = pad[:, :V]
+        K.colsum(d2, R, V, G(dec.bias))
+        K.gemm(2, d2, tn, V, Hd, R, out=G(dec.weight), accumulate=True, splits=K.splits_for(V, Hd, R))
+        d_tn = K.gemm(1, d2, W16(dec.weight), R, Hd, V)
+        d_t = K.layernorm_bwd(d_tn, t, R, Hd, tr.LayerNorm.weight.data, mean, rstd, G(tr.LayerNorm.weight), G(tr.LayerNorm.bias))
+        d_tpre = torch.empty((R, Hd), dtype=bf16, device=d_t.device)
+        K.scale_mask_rows(d_t, R, Hd, out=d_tpre, colsum=G(tr.dense.bias), gelu_in=t_pre)
+        K.gemm(2, d_tpre, x2, Hd, Hd, R, out=G(tr.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))
+        dx = K.gemm(1, d_tpre, W16(tr.dense.weight), R, Hd, Hd)
+        return None, dx.view(ctx.shp), None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """CrossEntropyLoss(ignore_index=-1) (agent.py:72).  Training: the logits buffer is consumed -- it is
+    overwritten in place with d(loss)/d(logits)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, count):
+        V = logits.shape[-1]
+        assert logits.dim() == 2 and logits.stride(-1) == 1 and logits.stride(0) % 8 == 0, \
+            "logits must be a (rows, V) view of a row-padded bf16 buffer (as produced by the MLM head)"
+        labels = labels.contiguous()
+        acc = torch.zeros(2, dtype=torch.float32, device=logits.device)
+        train = ctx.needs_input_grad[0]
+        scale = (1.0 / max(count, 1)) if count is not None else 1.0
+        K.cross_entropy(logits, V, labels, acc, scale, train)
+        if train and count is None:
+            n = logits.shape[0] * logits.stride(0)
+            K.scale_by_count(logits, n, acc, 1.0)
+        ctx.grad_buf = logits if train else None
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        buf = ctx.grad_buf
+        if buf is None:
+            return None, None, None
+        # d(loss)/d(logits) already sits in `buf` for an upstream gradient of 1, which is what
+        # loss = ls_mtm + ls_vtm (main_pretrain_mlm.py:163) delivers.  A different upstream scale (e.g. a
+        # GradScaler) is honoured when CrossEntropyFn.assume_unit_grad is False (costs one host sync).
+        if not CrossEntropyFn.assume_unit_grad:
+            gv = float(g)
+            if gv != 1.0:
+                K.scale_by_count(buf, buf.shape[0] * buf.stride(0), None, gv)
+        return buf, None, None
+
+
+CrossEntropyFn.assume_unit_grad = True

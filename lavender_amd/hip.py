@@ -1,0 +1,242 @@
+"""Tensor-level wrappers over the C ABI: each function enqueues ONE hand-written HIP kernel on the current
+torch stream.  torch is used only for device memory and the stream handle."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+bf16 = torch.bfloat16
+_seed_counter = [0x1234567]
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def next_seed():
+    """Fresh 32-bit dropout seed (host-side counter hashed; deterministic under torch.manual_seed order)."""
+    _seed_counter[0] = (_seed_counter[0] * 1664525 + 1013904223) & 0xFFFFFFFF
+    return _seed_counter[0]
+
+
+def reseed(seed):
+    _seed_counter[0] = (int(seed) * 2654435761 + 12345) & 0xFFFFFFFF
+
+
+def _ld(t):
+    assert t.stride(-1) == 1, "innermost dimension must be contiguous"
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, preact=None, gelu_in=None, dropout_p=0.0,
+         seed=0, row_scale=None, rows_per_group=1, residual=None, colsum=None, alpha=1.0, accumulate=False,
+         k_keep=None, k_rows_per_group=1, splits=1, ldc=None):
+    """layout 0: A[M,K] B[N,K]; 1: A[M,K] B[K,N]; 2: A[K,M] B[K,N].  Returns the (M, N) output view."""
+    dev = A.device
+    if out is None:
+        ldc = ldc or ((N + 7) // 8 * 8)
+        out = torch.empty((M, ldc), dtype=out_dtype, device=dev)
+    else:
+        ldc = _ld(out)
+    e = L.GemmEpilogue()
+    e.bias = _p(bias)
+    e.act = act
+    e.preact = _p(preact)
+    e.ldp = _ld(preact) if preact is not None else 0
+    e.gelu_in = _p(gelu_in)
+    e.ldg = _ld(gelu_in) if gelu_in is not None else 0
+    e.dropout_p = float(dropout_p)
+    e.seed = int(seed) & 0xFFFFFFFF
+    e.row_scale = _p(row_scale)
+    e.rows_per_group = int(rows_per_group)
+    e.residual = _p(residual)
+    e.ldr = _ld(residual) if residual is not None else 0
+    e.colsum = _p(colsum)
+    e.alpha = float(alpha)
+    e.out_mode = 2 if accumulate else (1 if out.dtype == torch.float32 else 0)
+    e.k_keep = _p(k_keep)
+    e.k_rows_per_group = int(k_rows_per_group)
+    L.check(L.lib.lav_gemm_bf16(_s(), layout, M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc, C.byref(e), splits),
+            "lav_gemm_bf16")
+    return out[:, :N] if out.shape[-1] != N else out
+
+
+def splits_for(M, N, K):
+    """split-K factor for weight-gradient GEMMs: enough blocks to fill 256 CUs twice."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    want = max(1, 512 // tiles)
+    return int(max(1, min(want, (K + 511) // 512)))
+
+
+def _gather(g):
+    if g is None:
+        return None
+    s = L.LnGather()
+    s.mode, s.H, s.W, s.C0 = 1, g[0], g[1], g[2]
+    return C.byref(s)
+
+
+def layernorm_fwd(x, rows, Cn, gamma, beta, eps, gather=None, out=None, want_stats=True):
+    dev = x.device
+    y = out if out is not None else torch.empty((rows, Cn), dtype=bf16, device=dev)
+    mean = torch.empty(rows, dtype=torch.float32, device=dev) if want_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=dev) if want_stats else None
+    ldx = gather[2] if gather is not None else _ld(x)
+    L.check(L.lib.lav_layernorm_fwd(_s(), rows, Cn, _p(x), ldx, _gather(gather), _p(gamma), _p(beta), float(eps), _p(y),
+                                    _ld(y), _p(mean), _p(rstd)), "lav_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dgamma, dbeta, gather=None, add_in=None, dx=None, dx2=None,
+                  row_scale=None, rows_per_group=1, dropout_p=0.0, seed=0, colsum=None):
+    dev = dy.device
+    if dx is None:
+        dx = torch.empty((rows * 4, Cn // 4) if gather is not None else (rows, Cn), dtype=bf16, device=dev)
+    ldx = gather[2] if gather is not None else _ld(x)
+    lddx = gather[2] if gather is not None else _ld(dx)
+    ex = None
+    if dx2 is not None or colsum is not None:
+        s = L.LnBwdExtra()
+        s.dx2 = _p(dx2)
+        s.lddx2 = _ld(dx2) if dx2 is not None else 0
+        s.row_scale = _p(row_scale)
+        s.rows_per_group = int(rows_per_group)
+        s.dropout_p = float(dropout_p)
+        s.seed = int(seed) & 0xFFFFFFFF
+        s.colsum = _p(colsum)
+        ex = C.byref(s)
+    L.check(L.lib.lav_layernorm_bwd(_s(), rows, Cn, _p(dy), _ld(dy), _p(x), ldx, _gather(gather), _p(gamma), _p(mean),
+                                    _p(rstd), _p(add_in), (_ld(add_in) if add_in is not None else 0), _p(dx), lddx,
+                                    _p(dgamma), _p(dbeta), ex), "lav_layernorm_bwd")
+    return dx
+
+
+def scale_mask_rows(x, rows, Cn, out=None, row_scale=None, rows_per_group=1, dropout_p=0.0, seed=0, colsum=None,
+                    gelu_in=None):
+    L.check(L.lib.lav_scale_mask_rows(_s(), rows, Cn, _p(x), _ld(x), _p(out), (_ld(out) if out is not None else 0),
+                                      _p(row_scale), int(rows_per_group), float(dropout_p), int(seed) & 0xFFFFFFFF,
+                                      _p(colsum), _p(gelu_in), (_ld(gelu_in) if gelu_in is not None else 0)),
+            "lav_scale_mask_rows")
+    return out
+
+
+def colsum(x, rows, Cn, out):
+    L.check(L.lib.lav_colsum_bf16(_s(), rows, Cn, _p(x), _ld(x), _p(out)), "lav_colsum_bf16")
+
+
+class Attn:
+    """Descriptor + scratch for one attention call (window or sequence mode)."""
+
+    def __init__(self, mode, heads, head_dim, **kw):
+        d = L.AttnDesc()
+        d.mode, d.heads, d.head_dim = mode, heads, head_dim
+        d.scale = float(head_dim) ** -0.5
+        for k, v in kw.items():
+            if k in ("bias_table", "key_mask"):
+                setattr(d, k, _p(v))
+            else:
+                setattr(d, k, v)
+        self.d = d
+        self._keep = kw
+
+    def lse_elems(self):
+        n = L.lib.lav_attention_lse_elems(C.byref(self.d))
+        if n == 0:
+            L.check(-1, "lav_attention_lse_elems")
+        return n
+
+    def fwd(self, qkv, out, lse):
+        L.check(L.lib.lav_attention_fwd(_s(), C.byref(self.d), _p(qkv), _p(out), _p(lse)), "lav_attention_fwd")
+
+    def bwd(self, qkv, out, dout, lse, dqkv, dbias):
+        L.check(L.lib.lav_attention_bwd(_s(), C.byref(self.d), _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(dbias)),
+                "lav_attention_bwd")
+
+
+def patch_im2col(img, B, T, H, W, frame_major):
+    out = torch.empty((B * T * (H // 4) * (W // 4), 96), dtype=bf16, device=img.device)
+    L.check(L.lib.lav_patch_im2col(_s(), _p(img), B, T, H, W, int(frame_major), _p(out)), "lav_patch_im2col")
+    return out
+
+
+def video_embed_fwd(feat, B, T, hw, Hd, cls, pos, len_, gamma, beta, eps, out, seq_rows):
+    rows = B * T * (1 + hw)
+    mean = torch.empty(rows, dtype=torch.float32, device=feat.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=feat.device)
+    L.check(L.lib.lav_video_embed_fwd(_s(), B, T, hw, Hd, _p(feat), _p(cls), _p(pos), _p(len_), _p(gamma), _p(beta),
+                                      float(eps), _p(out), int(seq_rows), _p(mean), _p(rstd)), "lav_video_embed_fwd")
+    return mean, rstd
+
+
+def video_embed_bwd(dout, seq_rows, feat, B, T, hw, Hd, cls, pos, len_, gamma, mean, rstd, dfeat, d_cls, d_pos, d_len,
+                    dgamma, dbeta):
+    L.check(L.lib.lav_video_embed_bwd(_s(), B, T, hw, Hd, _p(dout), int(seq_rows), _p(feat), _p(cls), _p(pos), _p(len_),
+                                      _p(gamma), _p(mean), _p(rstd), _p(dfeat), _p(d_cls), _p(d_pos), _p(d_len),
+                                      _p(dgamma), _p(dbeta)), "lav_video_embed_bwd")
+
+
+def text_embed_fwd(ids, n, X, Hd, word, pos, type0, gamma, beta, eps, dropout_p, seed):
+    dev = ids.device
+    out = torch.empty((n * X, Hd), dtype=bf16, device=dev)
+    mean = torch.empty(n * X, dtype=torch.float32, device=dev)
+    rstd = torch.empty(n * X, dtype=torch.float32, device=dev)
+    L.check(L.lib.lav_text_embed_fwd(_s(), n, X, Hd, _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), float(eps),
+                                     float(dropout_p), int(seed) & 0xFFFFFFFF, _p(out), _p(mean), _p(rstd)),
+            "lav_text_embed_fwd")
+    return out, mean, rstd
+
+
+def text_embed_bwd(ids, dout, n, X, Hd, word, pos, type0, gamma, mean, rstd, dropout_p, seed, d_word, d_pos, d_type0,
+                   dgamma, dbeta):
+    L.check(L.lib.lav_text_embed_bwd(_s(), n, X, Hd, _p(ids), _p(dout), _p(word), _p(pos), _p(type0), _p(gamma), _p(mean),
+                                     _p(rstd), float(dropout_p), int(seed) & 0xFFFFFFFF, _p(d_word), _p(d_pos),
+                                     _p(d_type0), _p(dgamma), _p(dbeta)), "lav_text_embed_bwd")
+
+
+def gather_rows(src, src_row, n_rows, Cn, out=None):
+    if out is None:
+        out = torch.empty((n_rows, Cn), dtype=bf16, device=src.device)
+    L.check(L.lib.lav_gather_rows(_s(), n_rows, Cn, _p(src), _ld(src), _p(src_row), _p(out), _ld(out)), "lav_gather_rows")
+    return out
+
+
+def gather_sum_rows(src, start, lst, n_out, Cn):
+    out = torch.empty((n_out, Cn), dtype=bf16, device=src.device)
+    L.check(L.lib.lav_gather_sum_rows(_s(), n_out, Cn, _p(src), _ld(src), _p(start), _p(lst), _p(out), _ld(out)),
+            "lav_gather_sum_rows")
+    return out
+
+
+def cross_entropy(logits2d, V, labels, loss_sum, grad_scale, write_grad):
+    rows = logits2d.shape[0]
+    L.check(L.lib.lav_cross_entropy_fwd_bwd(_s(), rows, V, _p(logits2d), _ld(logits2d), _p(labels), _p(loss_sum),
+                                            float(grad_scale), int(write_grad)), "lav_cross_entropy_fwd_bwd")
+
+
+def scale_by_count(x, n_elems, loss_sum, gscale):
+    L.check(L.lib.lav_scale_by_count(_s(), int(n_elems), _p(x), _p(loss_sum), float(gscale)), "lav_scale_by_count")
+
+
+def sumsq(g, n, out):
+    L.check(L.lib.lav_sumsq_f32(_s(), int(n), _p(g), _p(out)), "lav_sumsq_f32")
+
+
+def adamw(n, p, g, m, v, p16, block_group, lr4, wd4, b1, b2, eps, step, gradsq, max_norm, grad_div):
+    lr_a = (C.c_float * 4)(*[float(x) for x in lr4])
+    wd_a = (C.c_float * 4)(*[float(x) for x in wd4])
+    L.check(L.lib.lav_adamw_step(_s(), int(n), _p(p), _p(g), _p(m), _p(v), _p(p16), _p(block_group), lr_a, wd_a, float(b1),
+                                 float(b2), float(eps), int(step), _p(gradsq), float(max_norm), float(grad_div)),
+            "lav_adamw_step")
+
+
+def cast_bf16(src, dst, n):
+    L.check(L.lib.lav_cast_f32_to_bf16(_s(), int(n), _p(src), _p(dst)), "lav_cast_f32_to_bf16")
+
+
+def fill_droppath(n_blocks, B, keep_prob, seed, out):
+    L.check(L.lib.lav_fill_droppath(_s(), n_blocks, B, _p(keep_prob), int(seed) & 0xFFFFFFFF, _p(out)), "lav_fill_droppath")

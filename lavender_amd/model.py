@@ -1,0 +1,253 @@
+"""EncVideo / EncTxt / LAVENDER_Base -- MI355X-native mirror of the reference's model.py.
+
+Same class, attribute, method and state_dict key names; the arithmetic runs on the HIP
+engine.  Activations are bf16 (the reference trains under fp16 autocast / DeepSpeed fp16, agent.py:199-233);
+parameters are fp32 masters in a flat arena with a bf16 working copy (lavender_amd.arena).
+"""
+import os
+import weakref
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from . import hip as K
+from .arena import ParamArena
+from .bert import BertConfigLite, BertEmbeddings, BertEncoder, load_hf_state
+from .video_swin import LayerNorm, Linear, get_vidswin_model
+
+
+class EncVideo(nn.Module):
+    """model.py:5-93."""
+
+    def __init__(self, args, hidden_size):
+        super().__init__()
+        self.swin = get_vidswin_model(args)
+        self.latent_feat_size = self.swin.norm.normalized_shape[0]
+        self.img_feature_dim = hidden_size
+        self.swinbert = getattr(args, 'swinbert', False)
+        if self.swinbert:
+            raise NotImplementedError("the SwinBERT-initialised variant (model.py:33-35,52-66) is outside the pretrain hot path")
+        self.max_size_frame = getattr(args, 'max_size_frame', 6)
+        self.max_size_patch = getattr(args, 'max_size_patch', 14)
+        self.fc = Linear(self.latent_feat_size, self.img_feature_dim) if self.latent_feat_size != self.img_feature_dim else None
+        self.emb_cls = nn.Parameter(0.02 * torch.randn(1, 1, 1, hidden_size))
+        self.emb_pos = nn.Parameter(0.02 * torch.randn(1, 1, 1 + self.max_size_patch ** 2, hidden_size))
+        self.emb_len = nn.Parameter(0.02 * torch.randn(1, self.max_size_frame, 1, hidden_size))
+        self.emb_odr = nn.Parameter(0.02 * torch.randn(1, 1, 1, hidden_size))
+        self.norm = LayerNorm(hidden_size)
+        self.transform_normalize = None
+        self._arena_of = None
+
+    def forward(self, img, odr=None, vt_mask=None, taps=None):
+        if odr is not None:
+            raise NotImplementedError("frame-order embeddings (model.py:72-81) are not used by the pretrain path")
+        _B, _T, _C, _H, _W = img.shape
+        _h, _w = _H // 32, _W // 32
+        assert _T <= self.max_size_frame and _h * _w <= self.max_size_patch ** 2
+        if self.transform_normalize is not None:
+            img = self.transform_normalize(img)
+        arena = self._arena_of() if self._arena_of is not None else self.swin._arena()
+        tok, _ = self.swin.forward_tokens(img, frame_major=True, taps=taps)
+        f_img = E.VideoEmbedFn.apply(arena.anchor, tok, self, _B, _T, _h * _w)
+        m_img = torch.ones((_B, _T, 1 + _h * _w), dtype=torch.long, device=img.device)
+        if vt_mask is not None:
+            m_img = m_img * vt_mask
+        return f_img, m_img.view(_B, _T * (1 + _h * _w))
+
+
+class EncTxt(nn.Module):
+    """model.py:96-142 (txt_backbone_embed_only branch: BERT embeddings only)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        cfg = BertConfigLite.from_pretrained(args.txt_backbone)
+        if not getattr(args, "txt_backbone_embed_only", True):
+            raise NotImplementedError("a full text transformer in EncTxt (model.py:106-108) is not on the pretrain hot path")
+        self.emb_txt = BertEmbeddings(cfg)
+        self.txt_trsfr = None
+        self.mask_ext = None
+        self.size_vocab = cfg.vocab_size
+        sd = load_hf_state(args.txt_backbone, [("bert.embeddings.", "emb_txt."), ("embeddings.", "emb_txt.")])
+        if sd:
+            self.load_state_dict({k: v for k, v in sd.items() if "position_ids" not in k and "token_type_ids" not in k}, strict=False)
+        self._arena_of = None
+
+    def forward(self, txt, mask_txt=None, token_type_ids=None, position_ids=None, attn_mask_type="full"):
+        assert token_type_ids is None and position_ids is None, "custom token_type/position ids are not supported"
+        arena = self._arena_of()
+        p = self.emb_txt.dropout_p if self.training else 0.0
+        return E.TextEmbedFn.apply(arena.anchor, txt, self.emb_txt, p)
+
+
+class LAVENDER_Base(nn.Module):
+    """model.py:145-473 (hot-path methods + checkpoint contract)."""
+
+    def __init__(self, args, tokzr=None):
+        super().__init__()
+        self.args = args
+        self.enc_txt = EncTxt(args)
+        cfg = BertConfigLite.from_pretrained(args.fusion_encoder)
+        self.hidden_size = cfg.hidden_size
+        self.config = cfg
+        self.trsfr = BertEncoder(cfg)
+        if not getattr(args, "fusion_encoder_rand_init", False):
+            sd = load_hf_state(args.fusion_encoder, [("bert.encoder.", "")])
+            if sd:
+                self.trsfr.load_state_dict(sd, strict=False)
+        self.mask_ext = self._extended_mask
+        self.enc_img = EncVideo(args, self.hidden_size)
+        self.use_checkpoint = bool(getattr(args, "use_checkpoint", False))   # 288 GB HBM: activations are kept, no CPU offload
+        self.tokzr = tokzr
+        if tokzr is not None:
+            (self.cls_token_id, self.sep_token_id, self.pad_token_id, self.mask_token_id,
+             self.unk_token_id) = self.tokzr.convert_tokens_to_ids(
+                [self.tokzr.cls_token, self.tokzr.sep_token, self.tokzr.pad_token, self.tokzr.mask_token, self.tokzr.unk_token])
+            self.true_token_id = self.tokzr.convert_tokens_to_ids(["true"])[0]
+            self.false_token_id = self.tokzr.convert_tokens_to_ids(["false"])[0]
+        self._lav_arena = None
+        self.register_load_state_dict_post_hook(lambda m, k: m._mark_stale())
+
+    # ---- arena ---------------------------------------------------------------------------------
+    def _mark_stale(self):
+        if self._lav_arena is not None:
+            self._lav_arena.stale = True
+
+    def arena(self):
+        a = self._lav_arena
+        probe = self.enc_img.norm.weight
+        if a is None or not a.owns(probe):
+            if probe.device.type != "cuda":
+                raise RuntimeError("lavender_amd runs on the MI355X only: call model.cuda() first (there is no CPU path)")
+            a = ParamArena(self, probe.device)
+            self._lav_arena = a
+            ref = weakref.ref(a)
+            self.enc_img.swin._arena_ref = ref
+            self.enc_img._arena_of = ref
+            self.enc_txt._arena_of = ref
+            for lyr in self.trsfr.layer:
+                lyr._arena_of = ref
+            for m in self.children():
+                if hasattr(m, "predictions"):
+                    m._arena_of = ref
+        return a
+
+    build_arena = arena
+
+    def sync_weights(self):
+        """Call after modifying parameters in place outside the built-in optimizer."""
+        self.arena().sync_half()
+
+    # ---- reference surface -----------------------------------------------------------------------
+    @staticmethod
+    def _extended_mask(mask, shape=None, device=None, dtype=torch.float32):
+        """get_extended_attention_mask as used at model.py:136,239: (B,L) 0/1 -> additive (B,1,1,L)."""
+        return (1.0 - mask[:, None, None, :].to(dtype)) * torch.finfo(dtype).min
+
+    def go_feat(self, img, txt, mask, odr=None, vt_mask=None, attn_mask_type="full"):
+        self.arena().sync_half_if_stale()
+        feat_img, mask_img = self.enc_img(img, odr, vt_mask)
+        feat_txt = self.enc_txt(txt, mask_txt=mask, attn_mask_type=attn_mask_type)
+        return feat_img, mask_img, feat_txt, mask
+
+    def get_attn_mask(self, mask_img, mask_txt, attn_mask_type="full", mask_pretxt=None):
+        if attn_mask_type != "full" or mask_pretxt is not None:
+            raise NotImplementedError("seq2seq / pre-text masks (model.py:204-218) belong to the captioning path")
+        return torch.cat([mask_img, mask_txt], dim=1)
+
+    def _encode(self, feat, mask):
+        """feat (n, L, H) bf16, mask (n, L) 0/1 -> last_hidden_state (n, L, H)."""
+        arena = self.arena()
+        n, L, Hd = feat.shape
+        km = mask.to(torch.int32).contiguous()
+        x = feat.reshape(n * L, Hd)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        ph = self.config.hidden_dropout_prob if self.training else 0.0
+        pa = self.config.attention_probs_dropout_prob if self.training else 0.0
+        for lyr in self.trsfr.layer:
+            x = E.BertLayerFn.apply(arena.anchor, x, lyr, km, n, L, ph, pa)
+        return x.view(n, L, Hd)
+
+    def go_cross(self, feat_img, mask_img, feat_txt, mask_txt, attn_mask_type="full", feat_pretxt=None, mask_pretxt=None):
+        if feat_pretxt is not None:
+            raise NotImplementedError("prompt / task-token pre-text (model.py:228-232) is outside the pretrain hot path")
+        n = feat_img.shape[0]
+        ident = np.arange(n)
+        feat = E.PairSeqFn.apply(feat_img, feat_txt, ident, ident)
+        mask = self.get_attn_mask(mask_img, mask_txt, attn_mask_type=attn_mask_type)
+        assert feat.shape[1] == mask.shape[1], f"mask and feat must have the same length, got {feat.shape[1]} vs. {mask.shape[1]}"
+        return self._encode(feat, mask), None
+
+    def go_cross_pairs(self, feat_img, mask_img, feat_txt, mask_txt, vi, ti):
+        """go_cross on the pair list (video vi[k], text ti[k]) without materialising per-pair copies in Python
+        (replaces the list building + T.cat of main_pretrain_mlm.py:74-111)."""
+        feat = E.PairSeqFn.apply(feat_img, feat_txt, vi, ti)
+        vi_t = torch.as_tensor(np.asarray(vi), device=mask_img.device)
+        ti_t = torch.as_tensor(np.asarray(ti), device=mask_img.device)
+        mask = torch.cat([mask_img[vi_t], mask_txt[ti_t]], dim=1)
+        return self._encode(feat, mask), None
+
+    def prepro_txt_inputs(self, txt, mask_txt, feat_txt, task_name=None, prompt=None):
+        """model.py:292-307 with enable_task_token / enable_prompt off (the shipped pretrain config): identity."""
+        if getattr(self.args, "enable_task_token", False) or (prompt is not None and getattr(self.args, "enable_prompt", False)):
+            raise NotImplementedError("task tokens / prompts are outside the pretrain hot path")
+        return txt, mask_txt, feat_txt
+
+    # ---- checkpoint contract (model.py:352-429) ----------------------------------------------------
+    def load_ckpt(self, ckpt):
+        if ckpt == '':
+            print('===== Finished Init LAVENDER  =====')
+            return
+        elif not os.path.exists(ckpt):
+            print(f'Try to load pre-trained weights from {ckpt}, but file does not exists...')
+            return
+        print(f'Loading pre-trained weights from {ckpt}')
+        loaded = torch.load(ckpt, map_location='cpu')
+        self.__load_ckpt__(loaded)
+
+    def __load_ckpt__(self, loaded_state_dict):
+        own = self.state_dict()
+        model_keys, load_keys = set(own.keys()), set(loaded_state_dict.keys())
+        toload, mismatched = {}, []
+        for k in model_keys:
+            if k in load_keys:
+                if own[k].shape != loaded_state_dict[k].shape:
+                    mismatched.append((k, tuple(loaded_state_dict[k].shape), tuple(own[k].shape)))
+                else:
+                    toload[k] = loaded_state_dict[k]
+        print("You can ignore the keys with `position_ids` or from task heads")
+        strict = True
+        unexpected = load_keys - model_keys
+        if unexpected:
+            strict = False
+            print("=========================Unexpected==================================")
+            print(f"\tIn total {len(unexpected)}, {sorted(unexpected)}")
+        missing = model_keys - load_keys
+        if missing:
+            strict = False
+            print("===========================Missing===================================")
+            print(f"\tIn total {len(missing)}, {sorted(missing)}")
+        if mismatched:
+            strict = False
+            print("======================Shape Mismatched===============================")
+            print(f"\tIn total {len(mismatched)}, {sorted(mismatched)}")
+        self.load_state_dict(toload, strict=strict)
+        # emb_len / emb_pos resizing exactly as model.py:404-429 (getattr on a dict: always the defaults 6 / 14)
+        lf, lp = 6, 14
+        with torch.no_grad():
+            if lf < self.enc_img.max_size_frame:
+                self.enc_img.emb_len.data[:, :lf].copy_(loaded_state_dict["enc_img.emb_len"])
+            elif lf > self.enc_img.max_size_frame:
+                self.enc_img.emb_len.data.copy_(loaded_state_dict["enc_img.emb_len"][:, :self.enc_img.max_size_frame])
+            else:
+                print("enc_img.enc_len shape matched")
+            if lp < self.enc_img.max_size_patch:
+                self.enc_img.emb_pos.data[:, :, :lp].copy_(loaded_state_dict["enc_img.emb_pos"])
+            elif lp > self.enc_img.max_size_patch:
+                self.enc_img.emb_pos.data.copy_(loaded_state_dict["enc_img.emb_pos"][:, :, :self.enc_img.max_size_patch])
+            else:
+                print("enc_img.emb_pos shape matched")
+        self._mark_stale()

@@ -32,7 +32,7 @@ REF = "/root/reference"
 TMP = "/tmp/lav_golden"
 
 BERT_CFGS = {
-    "micro": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, vocab_size=8192),
+    "micro": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=8192),
     "b2l": dict(num_hidden_layers=2),
 }
 

@@ -31,7 +31,49 @@ def stats(t):
 
 
 BERT_CFGS = {
-    "micro": dict(hidden=128, layers=2, heads=4, ffn=512, vocab=8192),
+    "micro": dict(hidden=128, layers=2, heads=2, ffn=512, vocab=8192),
     "b2l": dict(hidden=768, layers=2, heads=12, ffn=3072, vocab=30522),
     "b12l": dict(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522),
 }
+
+
+class Tok:
+    """Tokenizer stub with the bert-base-uncased special ids (same as tests/golden/make_goldens.py)."""
+    cls_token = "[CLS]"; sep_token = "[SEP]"; pad_token = "[PAD]"; mask_token = "[MASK]"; unk_token = "[UNK]"
+    ids = {"[PAD]": 0, "[UNK]": 100, "[CLS]": 101, "[SEP]": 102, "[MASK]": 103, "true": 2995, "false": 6270}
+
+    def convert_tokens_to_ids(self, toks):
+        return [self.ids[t] for t in toks]
+
+
+def hf_cfg(bert):
+    c = BERT_CFGS[bert]
+    return dict(hidden_size=c["hidden"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+                intermediate_size=c["ffn"], vocab_size=c["vocab"])
+
+
+def make_args(swin, bert, B, size_img=224, **kw):
+    from lavender_amd.args import EasyDict
+    cfg = hf_cfg(bert)
+    a = EasyDict(vis_backbone_size=swin, size_img=size_img, vis_backbone_init="random", kinetics=400, txt_backbone=cfg,
+                 txt_backbone_embed_only=True, fusion_encoder=cfg, fusion_encoder_rand_init=True, use_checkpoint=False,
+                 size_patch=32, size_batch=B, tokenizer=cfg, enable_task_token=False, enable_prompt=False, temp=0.05,
+                 lr=2e-5, decay=1e-3, max_iter=100, max_grad_norm=1.0, deepspeed=False, vis_backbone_lr_mul=1.0,
+                 dataset=["x"], logging_steps=10, path_output="/tmp/lav_out", task="pretrain", seed=88)
+    a.update(kw)
+    return a
+
+
+def build_filled_model(swin, bert, B, device="cuda"):
+    """LAVENDER_Pretrain_MLM with every parameter filled deterministically from its key (same fill as the oracle)."""
+    import torch
+    from lavender_amd import LAVENDER_Pretrain_MLM
+    from oracle import lavender_ref as R
+    m = LAVENDER_Pretrain_MLM(make_args(swin, bert, B), Tok())
+    sd = m.state_dict()
+    new = {k: R.fill_tensor(k, v.shape) for k, v in sd.items() if v.is_floating_point()}
+    new["fc_mtm.predictions.decoder.bias"] = new["fc_mtm.predictions.bias"]
+    m.load_state_dict(new, strict=False)
+    m.to(device)
+    m.arena()
+    return m
