@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Headline benchmark: LAVENDER pretrain step (Video-Swin-B 5x224^2 + 32-token text + 12-layer fusion encoder +
+MLM head; forward + backward + clip + AdamW) on N MI355X GPUs of one node, data parallel.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one synthetic batch of 32 clips per GPU (inputs resident in HBM, labels
+already built).  Rank 0 prints ONE JSON line (contract in the task statement): `value` = whole-job samples/s,
+`roofline` = the dominant kernel (the bf16 MFMA GEMM) measured per launch with HIP events on its stream,
+`cpu_baseline` = the CPU oracle (restated reference path) timed on this box's host cores at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def flops_per_sample(E=128, depths=(2, 2, 18, 2), T=5, S=224, X=32, layers=12, hid=768, vocab=30522, n_seq=5, win=(8, 7, 7)):
+    """Algorithmic forward FLOPs per sample (SURVEY.md section 8d closed form: GEMM + attention MACs x2)."""
+    f = 0.0
+    n0 = T * (S // 4) ** 2
+    f += n0 * 2 * 96 * E
+    for s, d in enumerate(depths):
+        C = E * 2 ** s
+        side = S // 4 // 2 ** s
+        n = T * side * side
+        N = min(T, win[0]) * min(side, win[1]) * min(side, win[2])
+        f += d * n * (24 * C * C + 4 * N * C)
+        if s < 3:
+            f += (n // 4) * 2 * (4 * C) * (2 * C)
+    hw = (S // 32) ** 2
+    if 8 * E != hid:
+        f += T * hw * 2 * 8 * E * hid
+    L = T * (1 + hw) + X
+    f_seq = layers * L * (24 * hid * hid + 4 * L * hid)
+    f_head = X * (2 * hid * hid + 2 * hid * vocab)
+    return f + n_seq * (f_seq + f_head)
+
+
+def synth_batch(B, T, S, X, rank, device):
+    g = torch.Generator().manual_seed(1234 + rank)
+    img = torch.randn(B, T, 3, S, S, generator=g)
+    txt = torch.zeros(B, X, dtype=torch.long)
+    for b in range(B):
+        k = int(torch.randint(6, 28, (1,), generator=g))
+        txt[b, 0] = 101
+        txt[b, 1:1 + k] = torch.randint(1000, 30000, (k,), generator=g)
+        txt[b, 1 + k] = 102
+        txt[b, -1] = 103
+    return dict(img=img, txt=txt, mask=(txt != 0).long())
+
+
+def cpu_baseline(threads):
+    """Reference CPU path (restated: oracle/lavender_ref.py, parity-pinned to the real reference), Swin-B + 12L,
+    B=2, fp32, forward + loss + backward, on this box's host cores.  Bounded: 1 warm-up + 2 timed iterations."""
+    from oracle import lavender_ref as R
+    torch.set_num_threads(threads)
+    P = R.filled_params("base")
+    for v in P.values():
+        v.requires_grad_(True)
+    B = 2
+    batch = synth_batch(B, 5, 224, 32, 0, "cpu")
+    torch.manual_seed(88)
+    batch["txt"], batch["ans_mtm"] = R.masking(batch["txt"])
+    times = []
+    for it in range(3):
+        t0 = time.time()
+        np.random.seed(88)
+        out = R.pretrain_forward(P, batch, "base", 12)
+        l1, l2 = R.pretrain_loss(out)
+        (l1 + l2).backward()
+        for v in P.values():
+            v.grad = None
+        times.append(time.time() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": round(B / t, 4), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"Swin-B + 12L fusion + MLM head, B={B}, 5x224^2 + 32 tok, fp32, fwd+loss+bwd, median of 2 (after 1 warm-up), {t:.2f} s/iter"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--size", default="base")
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == a.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {a.gpus}"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    import lavender_amd as LA
+    from lavender_amd import hip as K
+    from lavender_amd.args import EasyDict
+    from lavender_amd.dist import set_seed
+
+    B, T, S, X = a.batch, 5, 224, 32
+    cfg = dict(num_hidden_layers=a.layers)
+    args = EasyDict(vis_backbone_size=a.size, size_img=S, vis_backbone_init="random", kinetics=600, txt_backbone=cfg,
+                    txt_backbone_embed_only=True, fusion_encoder=cfg, fusion_encoder_rand_init=True, use_checkpoint=False,
+                    size_patch=32, size_batch=B, tokenizer=cfg, enable_task_token=False, enable_prompt=False, temp=0.05,
+                    lr=2e-5, decay=1e-3, max_iter=10000, max_grad_norm=1.0, deepspeed=False, vis_backbone_lr_mul=1.0,
+                    dataset=["synthetic"], logging_steps=20, path_output="/tmp/lav_bench", task="pretrain", seed=88)
+
+    class Tok:
+        cls_token = "[CLS]"; sep_token = "[SEP]"; pad_token = "[PAD]"; mask_token = "[MASK]"; unk_token = "[UNK]"
+        ids = {"[PAD]": 0, "[UNK]": 100, "[CLS]": 101, "[SEP]": 102, "[MASK]": 103, "true": 2995, "false": 6270}
+
+        def convert_tokens_to_ids(self, toks):
+            return [self.ids[t] for t in toks]
+
+    set_seed(88)
+    model = LA.LAVENDER_Pretrain_MLM(args, Tok()).cuda()
+    model.arena()
+    agent = LA.Agent_Pretrain_MLM(args, model)
+    agent.prepare_dist_model()
+    nparam = sum(p.numel() for p in model.parameters())
+
+    # synthetic batches resident in HBM, labels built like the reference does (host masking, then H2D)
+    nb = 2
+    batches = []
+    torch.manual_seed(88)
+    for i in range(nb):
+        b = synth_batch(B, T, S, X, rank * 7 + i, "cuda")
+        b.update(agent.masking(b["txt"], b["mask"]))
+        batches.append(agent.prepare_batch(b))
+    np.random.seed(88)
+
+    def run_step(i):
+        return agent.step(batches[i % nb], True, sync=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        run_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        last = run_step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_vals = {k: float(v) for k, v in last.items()}
+
+    # ---- dominant-kernel roofline: every forward (NT) GEMM launch of one more step, HIP events on its stream ----
+    roof = None
+    if rank == 0:
+        rec = []
+        orig = K.gemm
+
+        def timed(layout, A, Bm, M, N, Kd, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(layout, A, Bm, M, N, Kd, **kw)
+            e1.record()
+            rec.append((layout, 2.0 * M * N * Kd, e0, e1))
+            return r
+        K.gemm = timed
+        import lavender_amd.engine as ENG
+        ENG.K.gemm = timed
+        run_step(0)
+        torch.cuda.synchronize()
+        K.gemm = orig
+        ENG.K.gemm = orig
+        by = {}
+        for layout, fl, e0, e1 in rec:
+            d = by.setdefault(layout, [0, 0.0, 0.0])
+            d[0] += 1; d[1] += fl; d[2] += e0.elapsed_time(e1) * 1e-3
+        n, fl, tm = by[0]
+        tot_fl = sum(v[1] for v in by.values()); tot_t = sum(v[2] for v in by.values())
+        roof = {"bound": "mfma", "kernel": "gemm_kernel<NT> (lav_gemm_bf16 layout 0)", "achieved": round(fl / tm / 1e12, 2),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tm / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n, "avg_launch_us": round(tm / n * 1e6, 2), "avg_launch_gflop": round(fl / n / 1e9, 3),
+                "all_gemm_layouts": {"launches": sum(v[0] for v in by.values()), "tflops": round(tot_fl / tot_t / 1e12, 2),
+                                     "gemm_time_ms_per_step": round(tot_t * 1e3, 2)}}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = world * B * a.steps / dt
+        fstep = 3.0 * flops_per_sample(**{"base": {}, "tiny": dict(E=96, depths=(2, 2, 6, 2)),
+                                          "large": dict(E=192)}.get(a.size, {}), layers=a.layers)
+        out = {"metric": "video-text samples/sec (node) pretrain step, Swin-B 5x224^2 + 32-tok", "value": round(value, 2),
+               "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"cfg2: Swin-{a.size}-K600-22k + {a.layers}-layer fusion + MLM head, main_pretrain_mlm path, "
+                                      f"fwd+bwd+clip+AdamW, dropout 0.1 / drop-path 0.2 on",
+                          "per_gpu_batch": B, "global_batch": B * world, "frames": T, "size_img": S, "size_txt": X,
+                          "parallelism": f"dp{world}", "params_M": round(nparam / 1e6, 2),
+                          "algorithmic_tflop_per_step_per_gpu": round(fstep * B / 1e12, 2),
+                          "step_mfma_frac": round(value / world * fstep / 1e12 / PEAK_BF16_TFLOPS, 4),
+                          "loss": loss_vals},
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,8 +95,8 @@ class Agent_Pretrain_MLM(Agent_Base):
         ans_idx = (ans_vtm == self.true_token_id).nonzero()[:, 1]
         return float((out_vtm == ans_idx).float().sum() / _B)
 
-    def step(self, batch, is_train=True):
-        """main_pretrain_mlm.py:145-176."""
+    def step(self, batch, is_train=True, sync=True):
+        """main_pretrain_mlm.py:145-176.  sync=False returns the two losses as device scalars (no host round trip)."""
         self.model.train() if is_train else self.model.eval()
         n_mtm = batch.get("_n_mtm") if isinstance(batch, dict) else None
         with torch.set_grad_enabled(is_train):
@@ -107,6 +107,8 @@ class Agent_Pretrain_MLM(Agent_Base):
         if is_train:
             ls = ls_mtm + ls_vtm
             self.backward_step(ls)
+            if not sync:
+                return {'mtm': ls_mtm.detach(), 'vtm': ls_vtm.detach()}
             return {'mtm': ls_mtm.item(), 'vtm': ls_vtm.item()}
         pred = torch.argmax(out_mtm, dim=-1)
         n = (ans_mtm != -1).sum()
