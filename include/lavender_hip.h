@@ -58,6 +58,8 @@ typedef struct lav_gemm_epilogue {
     int out_mode;             /* 0 bf16 store, 1 fp32 store, 2 fp32 atomicAdd */
     const float* k_keep;      /* layout 2 only: contraction rows whose k_keep[row / k_rows_per_group]==0 are skipped */
     int k_rows_per_group;
+    float* rowsum_a;          /* layout 2 only: fp32 [M] += alpha * sum_k A[k, m] -- the bias gradient sum(dy), fused
+                                 into the weight-gradient GEMM on the matrix cores (no extra pass over dy) */
 } lav_gemm_epilogue;
 
 int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B, long ldb,

@@ -95,10 +95,15 @@ __device__ __forceinline__ bf16x8 frag_read(const char* lds, int t16, int ks, in
     }
 }
 
-template <bool AK, bool BK>
-__global__ __launch_bounds__(NT_) void gemm_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// KG = number of 4-wave groups per block.  KG == 2 (weight gradients): the two groups walk alternate k-tiles of
+// the SAME output tile with private LDS stages and merge their accumulators through LDS -- twice the waves per
+// CU without doubling the number of fp32-atomic output tiles (the epilogue atomics are what caps split-K).
+template <bool AK, bool BK, int KG>
+__global__ __launch_bounds__(NT_ * KG) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int grp = KG == 1 ? 0 : (threadIdx.x >> 8);
+    char* smem = smem_all + grp * 65536;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
     // XCD-aware bijective remap: each XCD (block b -> XCD b % 8) walks a contiguous run of tiles, n fastest
@@ -121,22 +126,35 @@ __global__ __launch_bounds__(NT_) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // TN only: bias gradient = sum over the contraction of A's columns, computed on the matrix cores against a
+    // ones fragment by the wn==0 waves of the n0==0 blocks (every column of the product equals the row sum)
+    const bool do_rowsum = !AK && g.e.rowsum_a != nullptr && n0 == 0 && wn == 0;
+    f32x4 acc1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+    {
+        union { uint4 u; bf16x8 b; } o; o.u = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); ones = o.b;
+    }
+
     uint4 ra[4], rb[4];
     const float* keep = g.e.k_keep;
+    const int nit = (nk + KG - 1) / KG;                    // iterations per group (tiles kt = it*KG + grp; overrun tiles read as zeros)
     if (nk > 0) {
-        tile_load<AK>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid, keep, g.e.k_rows_per_group);
-        tile_load<BK>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid, keep, g.e.k_rows_per_group);
+        tile_load<AK>(ra, g.A, g.lda, m0, g.M, kbeg + grp * BKT, kend, tid, keep, g.e.k_rows_per_group);
+        tile_load<BK>(rb, g.B, g.ldb, n0, g.N, kbeg + grp * BKT, kend, tid, keep, g.e.k_rows_per_group);
         tile_store<AK>(ra, smem, tid);
         tile_store<BK>(rb, smem + 16384, tid);
     }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int it = 0; it < nit; ++it) {
+        const int cur = it & 1;
         char* la = smem + cur * 32768;
         char* lb = la + 16384;
-        if (kt + 1 < nk) {
-            tile_load<AK>(ra, g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BKT, kend, tid, keep, g.e.k_rows_per_group);
-            tile_load<BK>(rb, g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BKT, kend, tid, keep, g.e.k_rows_per_group);
+        if (it + 1 < nit) {
+            const int k0n = kbeg + ((it + 1) * KG + grp) * BKT;
+            tile_load<AK>(ra, g.A, g.lda, m0, g.M, k0n, kend, tid, keep, g.e.k_rows_per_group);
+            tile_load<BK>(rb, g.B, g.ldb, n0, g.N, k0n, kend, tid, keep, g.e.k_rows_per_group);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -150,27 +168,57 @@ __global__ __launch_bounds__(NT_) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (!AK && do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, acc1[i], 0, 0, 0);
+            }
         }
-        if (kt + 1 < nk) {
+        if (it + 1 < nit) {
             tile_store<AK>(ra, smem + (cur ^ 1) * 32768, tid);
             tile_store<BK>(rb, smem + (cur ^ 1) * 32768 + 16384, tid);
         }
         __syncthreads();
     }
 
-    // ---- stage the accumulator tile through LDS (fp32, row stride 132 floats) ----------------------
-    float* cl = (float*)smem;
+    if (!AK && do_rowsum && (lane & 15) == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-                int col = wn * 64 + j * 16 + (lane & 15);
-                cl[row * CSTRIDE + col] = acc[i][j][r];
+                const int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (row < g.M) atomicAdd(g.e.rowsum_a + row, acc1[i][r] * g.e.alpha);
             }
+    }
+    // ---- stage the accumulator tile through LDS (fp32, row stride 132 floats) ----------------------
+    float* cl = (float*)smem_all;
+    if (KG == 1 || grp == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                    int col = wn * 64 + j * 16 + (lane & 15);
+                    cl[row * CSTRIDE + col] = acc[i][j][r];
+                }
+    }
     __syncthreads();
+    if (KG == 2) {
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                        int col = wn * 64 + j * 16 + (lane & 15);
+                        cl[row * CSTRIDE + col] += acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+    }
 
     const lav_gemm_epilogue& e = g.e;
     const int cc = tid & 15;
@@ -184,9 +232,10 @@ __global__ __launch_bounds__(NT_) void gemm_kernel(GemmArgs g) {
             if (x < ncols) bias[x] = e.bias[gcol + x];
     }
     const bool full = ncols == 8;
+    const int etid = threadIdx.x;                           // all KG*256 threads share the epilogue
 #pragma unroll 1
-    for (int j = 0; j < 8; ++j) {
-        const int row = (tid >> 4) + 16 * j;
+    for (int j = 0; j < 8 / KG; ++j) {
+        const int row = (etid >> 4) + 16 * KG * j;
         const int grow = m0 + row;
         if (grow >= g.M || ncols <= 0) continue;
         float v[8];
@@ -249,15 +298,15 @@ __global__ __launch_bounds__(NT_) void gemm_kernel(GemmArgs g) {
     }
     if (e.colsum) {
         __syncthreads();
-        float* red = (float*)smem;                       // [16][128]
+        float* red = (float*)smem_all;                   // [16*KG][128]
 #pragma unroll
-        for (int x = 0; x < 8; ++x) red[(tid >> 4) * 128 + cc * 8 + x] = csum[x];
+        for (int x = 0; x < 8; ++x) red[(etid >> 4) * 128 + cc * 8 + x] = csum[x];
         __syncthreads();
-        if (tid < 128 && n0 + tid < g.N) {
+        if (etid < 128 && n0 + etid < g.N) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += red[r * 128 + tid];
-            atomicAdd(e.colsum + n0 + tid, s);
+            for (int r = 0; r < 16 * KG; ++r) s += red[r * 128 + etid];
+            atomicAdd(e.colsum + n0 + etid, s);
         }
     }
 }
@@ -277,6 +326,7 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     if (epi) g.e = *epi; else { g.e.alpha = 1.f; }
     if (g.e.alpha == 0.f) g.e.alpha = 1.f;
     if (splits < 1) splits = 1;
+    LAV_REQUIRE(!g.e.rowsum_a || layout == 2, "lav_gemm_bf16: rowsum_a is only defined for layout 2 (TN)");
     LAV_REQUIRE(splits == 1 || g.e.out_mode == 2, "lav_gemm_bf16: split-K needs out_mode=2 (fp32 atomic accumulate)");
     LAV_REQUIRE(g.e.out_mode != 0 || (ldc % 8) == 0, "lav_gemm_bf16: bf16 output needs ldc %% 8 == 0");
     LAV_REQUIRE(g.e.out_mode == 0 || (ldc % 4) == 0, "lav_gemm_bf16: fp32 output needs ldc %% 4 == 0");
@@ -289,14 +339,14 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     hipStream_t s = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        hipFuncSetAttribute((const void*)gemm_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        hipFuncSetAttribute((const void*)gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm_kernel<true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm_kernel<true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm_kernel<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         (void)hipGetLastError();
         attr_set = true;
     }
-    if (layout == 0) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, GEMM_LDS_BYTES, s, g);
-    else if (layout == 1) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, GEMM_LDS_BYTES, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, GEMM_LDS_BYTES, s, g);
+    if (layout == 0) hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, block, GEMM_LDS_BYTES, s, g);
+    else if (layout == 1) hipLaunchKernelGGL((gemm_kernel<true, false, 1>), grid, block, GEMM_LDS_BYTES, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<false, false, 2>), grid, dim3(NT_ * 2), 131072, s, g);
     return lav_check_launch("lav_gemm_bf16");
 }

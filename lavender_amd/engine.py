@@ -113,9 +113,8 @@ class SwinBlockFn(torch.autograd.Function):
         M, C = x.shape
         dy = dy.contiguous()
         # --- MLP branch: out = x_mid + s * fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------
-        K.scale_mask_rows(dy, M, C, row_scale=dp_mlp, rows_per_group=rpg, colsum=G(mlp.fc2.bias))
         K.gemm(2, dy, h, C, 4 * C, M, out=G(mlp.fc2.weight), accumulate=True, k_keep=dp_mlp, k_rows_per_group=rpg,
-               alpha=alpha if dp_mlp is not None else 1.0, splits=K.splits_for(C, 4 * C, M))
+               alpha=alpha if dp_mlp is not None else 1.0, splits=K.splits_for(C, 4 * C, M), rowsum_a=G(mlp.fc2.bias))
         dh = K.gemm(1, dy, W16(mlp.fc2.weight), M, 4 * C, C, gelu_in=h_pre, row_scale=dp_mlp, rows_per_group=rpg,
                     colsum=G(mlp.fc1.bias))
         K.gemm(2, dh, y2, 4 * C, C, M, out=G(mlp.fc1.weight), accumulate=True, splits=K.splits_for(4 * C, C, M))
@@ -124,14 +123,13 @@ class SwinBlockFn(torch.autograd.Function):
         d_mid = K.layernorm_bwd(d_y2, x_mid, M, C, blk.norm2.weight.data, mean2, rstd2, G(blk.norm2.weight), G(blk.norm2.bias),
                                 add_in=dy)
         # --- attention branch: x_mid = x + s * proj(attn(qkv(LN1(x)))) ---------------------------------
-        K.scale_mask_rows(d_mid, M, C, row_scale=dp_attn, rows_per_group=rpg, colsum=G(a.proj.bias))
         K.gemm(2, d_mid, ao, C, C, M, out=G(a.proj.weight), accumulate=True, k_keep=dp_attn, k_rows_per_group=rpg,
-               alpha=alpha if dp_attn is not None else 1.0, splits=K.splits_for(C, C, M))
+               alpha=alpha if dp_attn is not None else 1.0, splits=K.splits_for(C, C, M), rowsum_a=G(a.proj.bias))
         d_ao = K.gemm(1, d_mid, W16(a.proj.weight), M, C, C, row_scale=dp_attn, rows_per_group=rpg)
         dqkv = torch.empty_like(qkv)
         att.bwd(qkv, ao, d_ao, lse, dqkv, G(a.relative_position_bias_table))
-        K.colsum(dqkv, M, 3 * C, G(a.qkv.bias))
-        K.gemm(2, dqkv, y1, 3 * C, C, M, out=G(a.qkv.weight), accumulate=True, splits=K.splits_for(3 * C, C, M))
+        K.gemm(2, dqkv, y1, 3 * C, C, M, out=G(a.qkv.weight), accumulate=True, splits=K.splits_for(3 * C, C, M),
+               rowsum_a=G(a.qkv.bias))
         d_y1 = K.gemm(1, dqkv, W16(a.qkv.weight), M, C, 3 * C)
         dx = K.layernorm_bwd(d_y1, x, M, C, blk.norm1.weight.data, mean1, rstd1, G(blk.norm1.weight), G(blk.norm1.bias),
                              add_in=d_mid)
@@ -223,8 +221,8 @@ class VideoEmbedFn(torch.autograd.Function):
                           G(enc.norm.weight), G(enc.norm.bias))
         if enc.fc is None:
             return None, dfeat, None, None, None, None
-        K.colsum(dfeat, M, Hd, G(enc.fc.bias))
-        K.gemm(2, dfeat, tok, Hd, Cl, M, out=G(enc.fc.weight), accumulate=True, splits=K.splits_for(Hd, Cl, M))
+        K.gemm(2, dfeat, tok, Hd, Cl, M, out=G(enc.fc.weight), accumulate=True, splits=K.splits_for(Hd, Cl, M),
+               rowsum_a=G(enc.fc.bias))
         dtok = K.gemm(1, dfeat, W16(enc.fc.weight), M, Cl, Hd)
         return None, dtok, None, None, None, None
 
@@ -358,8 +356,7 @@ class BertLayerFn(torch.autograd.Function):
         d_cx = K.gemm(1, d_dense1, W16(ao.dense.weight), R, Hd, Hd)
         dqkv = torch.empty_like(qkv)
         att.bwd(qkv, cx, d_cx, lse, dqkv, None)
-        K.colsum(dqkv, R, 3 * Hd, gbqkv)
-        K.gemm(2, dqkv, x, 3 * Hd, Hd, R, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, R))
+        K.gemm(2, dqkv, x, 3 * Hd, Hd, R, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, R), rowsum_a=gbqkv)
         dx = K.gemm(1, dqkv, wqkv16, R, Hd, 3 * Hd, residual=d_pre1)
         return None, dx, None, None, None, None, None, None
 
@@ -402,8 +399,7 @@ class MLMHeadFn(torch.autograd.Function):
             pad = torch.zeros((R, ld), dtype=bf16, device=d2.device)
             pad[:, :V].copy_(d2)
             d2 = pad[:, :V]
-        K.colsum(d2, R, V, G(dec.bias))
-        K.gemm(2, d2, tn, V, Hd, R, out=G(dec.weight), accumulate=True, splits=K.splits_for(V, Hd, R))
+        K.gemm(2, d2, tn, V, Hd, R, out=G(dec.weight), accumulate=True, splits=K.splits_for(V, Hd, R), rowsum_a=G(dec.bias))
         d_tn = K.gemm(1, d2, W16(dec.weight), R, Hd, V)
         d_t = K.layernorm_bwd(d_tn, t, R, Hd, tr.LayerNorm.weight.data, mean, rstd, G(tr.LayerNorm.weight), G(tr.LayerNorm.bias))
         d_tpre = torch.empty((R, Hd), dtype=bf16, device=d_t.device)

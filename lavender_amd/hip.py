@@ -35,7 +35,7 @@ def _ld(t):
 
 def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, preact=None, gelu_in=None, dropout_p=0.0,
          seed=0, row_scale=None, rows_per_group=1, residual=None, colsum=None, alpha=1.0, accumulate=False,
-         k_keep=None, k_rows_per_group=1, splits=1, ldc=None):
+         k_keep=None, k_rows_per_group=1, splits=1, ldc=None, rowsum_a=None):
     """layout 0: A[M,K] B[N,K]; 1: A[M,K] B[K,N]; 2: A[K,M] B[K,N].  Returns the (M, N) output view."""
     dev = A.device
     if out is None:
@@ -61,16 +61,20 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
     e.out_mode = 2 if accumulate else (1 if out.dtype == torch.float32 else 0)
     e.k_keep = _p(k_keep)
     e.k_rows_per_group = int(k_rows_per_group)
+    e.rowsum_a = _p(rowsum_a)
     L.check(L.lib.lav_gemm_bf16(_s(), layout, M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc, C.byref(e), splits),
             "lav_gemm_bf16")
     return out[:, :N] if out.shape[-1] != N else out
 
 
 def splits_for(M, N, K):
-    """split-K factor for weight-gradient GEMMs: enough blocks to fill 256 CUs twice."""
+    """split-K factor for weight-gradient GEMMs.  Measured on MI355X (tools/tn_probe.py): the 8-wave TN kernel is
+    fastest at about 190-260 blocks (<= one per CU); every extra split adds a full fp32-atomic output tile."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    want = max(1, 512 // tiles)
-    return int(max(1, min(want, (K + 511) // 512)))
+    if tiles >= 200:
+        return 1
+    s = 3 if 128 < tiles <= 160 else max(1, int(round(208.0 / tiles)))
+    return int(max(1, min(s, 128, (K + 255) // 256)))
 
 
 def _gather(g):

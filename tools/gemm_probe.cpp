@@ -57,7 +57,7 @@ static int check(int layout, int M, int N, int K, int splits) {
     return bad != 0;
 }
 
-static void bench(int layout, int M, int N, int K, int splits, const char* name) {
+static void bench(int layout, int M, int N, int K, int splits, const char* name, int force_mode = -1) {
     long lda = layout == 2 ? M : K, ldb = layout == 0 ? K : N, arows = layout == 2 ? K : M, brows = layout == 0 ? N : K;
     long ldc = (N + 7) / 8 * 8;
     void *dA, *dB, *dC;
@@ -68,6 +68,7 @@ static void bench(int layout, int M, int N, int K, int splits, const char* name)
     hipMemcpy(dB, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     hipMemset(dC, 0, (long)M * ldc * 4);
     lav_gemm_epilogue e; memset(&e, 0, sizeof(e)); e.alpha = 1.f; e.out_mode = splits > 1 ? 2 : 0;
+    if (force_mode >= 0) e.out_mode = force_mode;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3; ++i) lav_gemm_bf16(nullptr, layout, M, N, K, dA, lda, dB, ldb, dC, ldc, &e, splits);
     hipEventRecord(a, nullptr);
@@ -102,6 +103,17 @@ int main(int argc, char** argv) {
         bench(2, 2048, 512, 31360, 8, "swin s3 fc1 dW");
         bench(2, 3072, 768, 36096, 8, "bert ffn1 dW");
         bench(2, 384, 128, 501760, 64, "swin s1 qkv dW");
+        bench(2, 3072, 768, 36096, 1, "bert ffn1 dW store f32", 1);
+        bench(2, 3072, 768, 36096, 1, "bert ffn1 dW atomic", 2);
+        bench(2, 3072, 768, 36096, 3, "bert ffn1 dW atomic s3", 2);
+        bench(0, 3072, 768, 36096, 1, "same shape NT store f32", 1);
+        bench(0, 3072, 768, 36096, 1, "same shape NT bf16", 0);
+        bench(1, 3072, 768, 36096, 1, "same shape NN store f32", 1);
+        bench(2, 384, 128, 501760, 167, "swin s1 qkv dW s167", 2);
+        bench(2, 384, 128, 501760, 32, "swin s1 qkv dW s32", 2);
+        bench(2, 512, 128, 501760, 128, "swin s1 fc1 dW s128", 2);
+        bench(2, 2048, 512, 31360, 4, "swin s3 fc1 dW s4", 2);
+        bench(2, 2048, 512, 31360, 1, "swin s3 fc1 dW s1 store", 1);
     }
     return fails != 0;
 }
