@@ -136,6 +136,15 @@ typedef struct lav_attn_desc {
     const int32_t* key_mask;  /* int32 (n_seq, L) 1 = attend, 0 = masked; or NULL */
     float dropout_p; uint32_t seed;
     float scale;              /* head_dim^-0.5 */
+    /* window mode, N <= 256: optional precomputed tables (see lav_attention_window_tables / _build_bias).  When
+     * `comb` is non-NULL the kernels read token rows from tok_table and the (bias + shift mask + key padding)
+     * term from the fragment-ordered bf16 tables instead of re-deriving them per element. */
+    const int32_t* tok_table; /* int32 (windows_per_sample, 256): token row within the sample, -1 = padding */
+    const uint8_t* win_type;  /* uint8 (windows_per_sample): mask type of the window (which shifted axes are last) */
+    const uint8_t* type_region; /* uint8 (n_types, 256): shift-region id of in-window token i for that type */
+    int n_types;
+    const void* comb;         /* bf16 (n_types, heads, 8 q-tiles, 8 k-tiles, 64 lanes, 16): keys x queries fragments */
+    const void* combT;        /* same, queries x keys fragments (dK/dV pass) */
 } lav_attn_desc;
 
 int lav_attention_fwd(void* stream, const lav_attn_desc* d, const void* qkv, void* out, float* lse);
@@ -143,6 +152,9 @@ int lav_attention_fwd(void* stream, const lav_attn_desc* d, const void* qkv, voi
 int lav_attention_bwd(void* stream, const lav_attn_desc* d, const void* qkv, const void* out, const void* dout,
                       const float* lse, void* dqkv, float* dbias_table);
 size_t lav_attention_lse_elems(const lav_attn_desc* d);
+/* Fills d->comb and d->combT (each n_types*heads*8*8*64*16 bf16) from the current bias table: value(q,k) =
+ * table[index(q,k), head] + (region(q) != region(k) ? -100 : 0), -30000 for padded keys (video_swin.py:153-160). */
+int lav_attention_build_bias(void* stream, const lav_attn_desc* d);
 
 /* ---------------------------------------------------------------------------------------------
  * Patch embedding im2col (PatchEmbed3D, video_swin.py:388-405): (B,3,T,H,W) fp32 NCDHW clip ->

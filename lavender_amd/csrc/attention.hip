@@ -11,29 +11,7 @@
 // row-major and is read with ds_read_b64_tr_b16 (hardware transpose) as the A operand of O^T = V^T P^T.
 #include "attn_common.h"
 
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
-
-template <int HD>
-__device__ __forceinline__ int vrow_off(int row, int slot) {
-    if (HD == 32) return row * 64 + (slot << 4);
-    return row * 128 + ((slot ^ (((row >> 1) & 1) << 2)) << 4);
-}
-
-// A-operand (32 rows of the transposed tile = 32 d-values, 16 keys) from a row-major [key][HD] LDS tile.
-// lane (j = l&31 -> d = d0 + j, hi): keys key0 + {4hi..4hi+3} and key0 + 8 + {4hi..4hi+3}
-template <int HD>
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int key0, int d0, int lane) {
-    const int i = lane & 15, dhalf = (lane >> 4) & 1, hi = lane >> 5;
-    const int r = i >> 2, c = i & 3;
-    const int dcol = d0 + 16 * dhalf + 4 * c;                 // first of 4 d-columns this lane's address covers
-    const int slot = dcol >> 3, sub = (dcol & 7) * 2;
-    const int row0 = key0 + 4 * hi + r;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + vrow_off<HD>(row0, slot) + sub));
-    s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + vrow_off<HD>(row0 + 8, slot) + sub));
-    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-    u.s.a = lo; u.s.b = hi4;
-    return u.v;
-}
+#define LOG2E 1.4426950408889634f
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -148,11 +126,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                         const int infs[4] = {inf.x, inf.y, inf.z, inf.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float v = s[kt][r4 * 4 + e] * a.d.scale;
+                            float v = s[kt][r4 * 4 + e] * (a.d.scale * LOG2E);          // exp2 domain
                             if (MODE == 0) {
                                 const int kcode = infs[e] & 0xffff, kreg = infs[e] >> 16;
-                                v += tbl[q_code - kcode + a.tbl_const];
-                                if (kreg != q_reg) v += -100.0f;
+                                v += tbl[q_code - kcode + a.tbl_const] * LOG2E;
+                                if (kreg != q_reg) v += -100.0f * LOG2E;
                             } else {
                                 v += __int_as_float(infs[e]);
                             }
@@ -165,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float m_new = fmaxf(m_run, mx);
                 const float m_use = m_new == -INFINITY ? 0.f : m_new;
-                const float alpha = __expf(m_run - m_use);           // m_run = -inf -> 0
+                const float alpha = fast_exp2(m_run - m_use);         // m_run = -inf -> 0
                 l_run *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < HD / 32; ++dt)
@@ -179,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     if (k0 >= kl_keys) continue;
                     float p[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { p[r] = __expf(s[kt][r] - m_use); l_run += p[r]; }
+                    for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(s[kt][r] - m_use); l_run += p[r]; }
                     if (MODE == 1 && a.d.dropout_p > 0.f) {
                         const float inv = 1.f / (1.f - a.d.dropout_p);
                         const uint64_t base = ((uint64_t)(prob * a.d.heads + head) * (uint64_t)N + (uint64_t)q) * (uint64_t)N;
@@ -217,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     w.y = pack2(o[dt][r4 * 4 + 2] * inv_l, o[dt][r4 * 4 + 3] * inv_l);
                     *(uint2*)(op + d) = w;
                 }
-            if (a.lse && hi == 0) a.lse[(long)blockIdx.x * a.Npad + q] = m_run + __logf(l_tot);
+            if (a.lse && hi == 0) a.lse[(long)blockIdx.x * a.Npad + q] = m_run + log2f(l_tot);   // log2 domain
         }
     }
 }
@@ -340,18 +318,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a, float* del
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = r4 * 4 + e;
-                        float v = s[r] * a.d.scale;
+                        float v = s[r] * (a.d.scale * LOG2E);
                         int bidx = 0;
                         if (MODE == 0) {
                             const int kcode = infs[e] & 0xffff, kreg = infs[e] >> 16;
                             bidx = q_code - kcode + a.tbl_const;
-                            v += tbl[bidx];
-                            if (kreg != q_reg) v += -100.0f;
+                            v += tbl[bidx] * LOG2E;
+                            if (kreg != q_reg) v += -100.0f * LOG2E;
                         } else {
                             v += __int_as_float(infs[e]);
                         }
                         const bool valid = q_ok && (kc0 + kb + e < N);
-                        float p = valid ? __expf(v - lse) : 0.f;
+                        float p = valid ? fast_exp2(v - lse) : 0.f;
                         float g = dp[r];
                         if (MODE == 1 && a.d.dropout_p > 0.f)
                             g = lav_keep(a.d.seed, base + (kc0 + kb + e), a.thresh) ? g * inv : 0.f;
@@ -511,16 +489,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a, const flo
                     for (int e = 0; e < 4; ++e) {
                         const int r = r4 * 4 + e;
                         const int q = qc0 + qb + e;
-                        float v = s[r] * a.d.scale;
+                        float v = s[r] * (a.d.scale * LOG2E);
                         if (MODE == 0) {
                             const int qcode = infs[e] & 0xffff, qreg = infs[e] >> 16;
-                            v += tbl[qcode - k_code + a.tbl_const];
-                            if (qreg != k_reg) v += -100.0f;
+                            v += tbl[qcode - k_code + a.tbl_const] * LOG2E;
+                            if (qreg != k_reg) v += -100.0f * LOG2E;
                         } else {
                             v += k_add;
                         }
                         const bool valid = k_ok && q < N;
-                        const float p = valid ? __expf(v - ls[e]) : 0.f;
+                        const float p = valid ? fast_exp2(v - ls[e]) : 0.f;
                         float g = dp[r], pdrop = p;
                         if (MODE == 1 && a.d.dropout_p > 0.f) {
                             const uint64_t idx = ((uint64_t)(prob * a.d.heads + head) * (uint64_t)N + (uint64_t)q) * (uint64_t)N + (uint64_t)key;
@@ -567,7 +545,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a, const flo
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int attn_setup(const lav_attn_desc* d, AttnArgs& a, int& problems) {
+int attn_setup(const lav_attn_desc* d, AttnArgs& a, int& problems) {
     LAV_REQUIRE(d, "attention: null descriptor");
     memset(&a, 0, sizeof(a));
     a.d = *d;
@@ -596,6 +574,15 @@ static int attn_setup(const lav_attn_desc* d, AttnArgs& a, int& problems) {
         a.N = d->L;
         problems = d->n_seq;
     }
+    if (d->mode == 0) {
+        a.nWs = a.nWd * a.nWh * a.nWw;
+        a.tps = d->D * d->H * d->W;
+        if (d->comb || d->combT) {
+            LAV_REQUIRE(a.N <= 256, "attention(window): the persistent path needs N <= 256 (got %d)", a.N);
+            LAV_REQUIRE(d->comb && d->combT && d->tok_table && d->win_type && d->type_region && d->n_types > 0,
+                        "attention(window): comb/combT/tok_table/win_type/type_region must be given together");
+        }
+    }
     a.nqt = (a.N + 31) / 32;
     a.Npad = a.nqt * 32;
     a.thresh = lav_drop_thresh(d->dropout_p);
@@ -621,6 +608,7 @@ extern "C" int lav_attention_fwd(void* stream, const lav_attn_desc* d, const voi
     if (int rc = attn_setup(d, a, problems)) return rc;
     LAV_REQUIRE(qkv && out, "lav_attention_fwd: null pointer");
     a.qkv = (const bf16_t*)qkv; a.o_w = (bf16_t*)out; a.lse = lse;
+    if (d->mode == 0 && d->comb) return win_persistent_fwd(stream, a);
     hipStream_t s = (hipStream_t)stream;
     const int KL = d->mode == 0 ? WIN_KL : SEQ_KL;
     const int qgroups = (a.nqt + 3) / 4;
@@ -648,6 +636,7 @@ extern "C" int lav_attention_bwd(void* stream, const lav_attn_desc* d, const voi
     a.qkv = (const bf16_t*)qkv; a.out = (const bf16_t*)out; a.dout = (const bf16_t*)dout; a.lse = (float*)lse;
     a.dqkv = (bf16_t*)dqkv; a.dbias = dbias_table;
     float* delta = (float*)lse + (size_t)problems * d->heads * a.Npad;
+    if (d->mode == 0 && d->comb) return win_persistent_bwd(stream, a, delta);
     hipStream_t s = (hipStream_t)stream;
     const int qgroups = (a.nqt + 3) / 4;
     if (d->mode == 0) {

@@ -20,7 +20,24 @@ struct AttnArgs {
     int tbl_rows, tbl_const, cstride_d, cstride_h;   // bias-table geometry
     int R;            // 32-row tiles per wave
     uint32_t thresh;
+    int nWs, tps;     // windows per sample, tokens per sample (fast window path)
 };
+
+int attn_setup(const lav_attn_desc* d, AttnArgs& a, int& problems);
+int win_persistent_fwd(void* stream, const AttnArgs& a);
+int win_persistent_bwd(void* stream, const AttnArgs& a, float* delta);
+
+// fast window path: token rows from the precomputed per-window table instead of div/mod chains
+__device__ __forceinline__ int tok_row(const AttnArgs& a, int win, int i) {
+    const int ws = win % a.nWs, b = win / a.nWs;
+    return a.d.tok_table[ws * 256 + i] + b * a.tps;
+}
+// fragment-ordered bias+mask tile: 16 consecutive bf16 per lane (two 16-byte loads)
+__device__ __forceinline__ void comb_tile(const bf16_t* base, int tile, int lane, float* c) {
+    const uint4* p = (const uint4*)(base + ((long)tile * 64 + lane) * 16);
+    uint4 u0 = p[0], u1 = p[1];
+    unpack8(u0, c); unpack8(u1, c + 8);
+}
 
 __device__ __forceinline__ int tile_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -66,3 +83,28 @@ __device__ __forceinline__ bf16x8 pack_frag(const float* p) {
 __device__ __forceinline__ bf16x8 frag2(uint2 lo, uint2 hi) {
     union { uint4 u; bf16x8 b; } x; x.u = make_uint4(lo.x, lo.y, hi.x, hi.y); return x.b;
 }
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+template <int HD>
+__device__ __forceinline__ int vrow_off(int row, int slot) {
+    if (HD == 32) return row * 64 + (slot << 4);
+    return row * 128 + ((slot ^ (((row >> 1) & 1) << 2)) << 4);
+}
+
+// A-operand (32 rows of the transposed tile = 32 d-values, 16 keys) from a row-major [key][HD] LDS tile.
+// lane (j = l&31 -> d = d0 + j, hi): keys key0 + {4hi..4hi+3} and key0 + 8 + {4hi..4hi+3}
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int key0, int d0, int lane) {
+    const int i = lane & 15, dhalf = (lane >> 4) & 1, hi = lane >> 5;
+    const int r = i >> 2, c = i & 3;
+    const int dcol = d0 + 16 * dhalf + 4 * c;                 // first of 4 d-columns this lane's address covers
+    const int slot = dcol >> 3, sub = (dcol & 7) * 2;
+    const int row0 = key0 + 4 * hi + r;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + vrow_off<HD>(row0, slot) + sub));
+    s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + vrow_off<HD>(row0 + 8, slot) + sub));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi4;
+    return u.v;
+}
+

@@ -35,7 +35,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, Na
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+// two floats -> packed bf16 pair (lo = a, hi = b), round-to-nearest-even in ONE VALU op (gfx950 v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // raw v_exp_f32
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
@@ -59,8 +65,11 @@ __device__ __forceinline__ uint32_t lav_mix(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ bool lav_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
-    uint32_t h = lav_mix((uint32_t)idx * 0x9E3779B9u + seed) ^ lav_mix((uint32_t)(idx >> 32) + 0x85ebca6bu);
-    return lav_mix(h) >= thresh;                           // P(keep) = 1 - thresh / 2^32
+    // one multiply-xorshift round per element (6 VALU ops): plenty for dropout masks, and the mask costs less than
+    // the softmax it is applied to (the 3-round version was 48 % of the fusion-attention forward)
+    uint32_t h = (uint32_t)idx * 0x9E3779B1u + seed + (uint32_t)(idx >> 32) * 0x85EBCA77u;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
+    return h >= thresh;                           // P(keep) = 1 - thresh / 2^32
 }
 static inline uint32_t lav_drop_thresh(float p) {
     double t = (double)p * 4294967296.0;

@@ -133,6 +133,45 @@ def colsum(x, rows, Cn, out):
     L.check(L.lib.lav_colsum_bf16(_s(), rows, Cn, _p(x), _ld(x), _p(out)), "lav_colsum_bf16")
 
 
+_WIN_TABLES = {}
+
+
+def window_tables(device, D, H, W, window, shift):
+    """Host-side geometry tables of the fast window-attention path (cached per geometry):
+    token row of (window, in-window index) in the un-rolled tensor (roll + window_partition of
+    video_swin.py:82-86,218-227 as a lookup), the mask type of every window and the shift-region id of every
+    in-window token per type (compute_mask, video_swin.py:290-305, in closed form)."""
+    key = (str(device), D, H, W, tuple(window), tuple(shift))
+    if key in _WIN_TABLES:
+        return _WIN_TABLES[key]
+    import numpy as np
+    wd, wh, ww = window
+    sd, sh, sw = shift
+    N = wd * wh * ww
+    assert N <= 256
+    nd, nh, nw = D // wd, H // wh, W // ww
+    bd, bh, bw = np.meshgrid(np.arange(nd), np.arange(nh), np.arange(nw), indexing="ij")
+    bd, bh, bw = bd.reshape(-1, 1), bh.reshape(-1, 1), bw.reshape(-1, 1)
+    i_d, i_h, i_w = np.meshgrid(np.arange(wd), np.arange(wh), np.arange(ww), indexing="ij")
+    i_d, i_h, i_w = i_d.reshape(1, -1), i_h.reshape(1, -1), i_w.reshape(1, -1)
+    src_d, src_h, src_w = (bd * wd + i_d + sd) % D, (bh * wh + i_h + sh) % H, (bw * ww + i_w + sw) % W
+    tok = np.full((nd * nh * nw, 256), -1, dtype=np.int32)
+    tok[:, :N] = (src_d * H + src_h) * W + src_w
+    flags = ((bd[:, 0] == nd - 1) & (sd > 0)) * 4 + ((bh[:, 0] == nh - 1) & (sh > 0)) * 2 + ((bw[:, 0] == nw - 1) & (sw > 0)) * 1
+    uniq = sorted(set(flags.tolist()))
+    wtype = np.array([uniq.index(f) for f in flags.tolist()], dtype=np.uint8)
+    region = np.zeros((len(uniq), 256), dtype=np.uint8)
+    for t, f in enumerate(uniq):
+        rd = (1 + (i_d[0] >= wd - sd)) if (f & 4) else 0 * i_d[0]
+        rh = (1 + (i_h[0] >= wh - sh)) if (f & 2) else 0 * i_h[0]
+        rw = (1 + (i_w[0] >= ww - sw)) if (f & 1) else 0 * i_w[0]
+        region[t, :N] = rd * 9 + rh * 3 + rw
+    out = dict(tok=torch.from_numpy(tok).to(device), wtype=torch.from_numpy(wtype).to(device),
+               region=torch.from_numpy(region).to(device), ntypes=len(uniq))
+    _WIN_TABLES[key] = out
+    return out
+
+
 class Attn:
     """Descriptor + scratch for one attention call (window or sequence mode)."""
 
@@ -147,6 +186,18 @@ class Attn:
                 setattr(d, k, v)
         self.d = d
         self._keep = kw
+        if mode == 0 and kw["wd"] * kw["wh"] * kw["ww"] <= 256:
+            # fast path: precomputed token rows + fragment-ordered (bias + mask) tables, rebuilt from the
+            # current bias table (one small kernel per call site per step)
+            dev = kw["bias_table"].device
+            t = window_tables(dev, kw["D"], kw["H"], kw["W"], (kw["wd"], kw["wh"], kw["ww"]), (kw["sd"], kw["sh"], kw["sw"]))
+            n = t["ntypes"] * heads * 64 * 64 * 16
+            self.comb = torch.empty(n, dtype=bf16, device=dev)
+            self.combT = torch.empty(n, dtype=bf16, device=dev)
+            d.tok_table, d.win_type, d.type_region, d.n_types = _p(t["tok"]), _p(t["wtype"]), _p(t["region"]), t["ntypes"]
+            d.comb, d.combT = _p(self.comb), _p(self.combT)
+            self._tables = t
+            L.check(L.lib.lav_attention_build_bias(_s(), C.byref(d)), "lav_attention_build_bias")
 
     def lse_elems(self):
         n = L.lib.lav_attention_lse_elems(C.byref(self.d))
