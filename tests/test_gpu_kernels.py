@@ -1,0 +1,369 @@
+"""GPU: every HIP kernel family, called through the C ABI, against a plain fp32 reference of the same op
+(torch on CPU/GPU for generic math, oracle/lavender_ref.py for the LAVENDER-specific ops).
+
+bf16 tolerances: GEMM-like outputs are compared with |d| <= atol + rtol*|ref| at bf16 resolution (2^-8);
+index / mask / counting paths are exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+bf16 = torch.bfloat16
+
+
+def K():
+    from lavender_amd import hip
+    return hip
+
+
+def rb(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(bf16).cuda()
+
+
+def close(a, b, atol=2e-2, rtol=2e-2, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    lim = atol + rtol * b.abs()
+    assert (err <= lim).all(), f"{what}: max err {err.max().item():.4g}, worst excess {(err - lim).max().item():.4g}"
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 136, 96), (77, 40, 160), (384, 250, 768), (1000, 384, 128)])
+def test_gemm_layouts(layout, shape):
+    M, N, Kd = shape
+    pad8 = lambda n: (n + 7) // 8 * 8                      # the ABI wants 16-byte rows: ragged extents live in padded buffers
+    A = rb(Kd, pad8(M))[:, :M] if layout == 2 else rb(M, Kd)
+    B = rb(N, Kd, seed=1) if layout == 0 else rb(Kd, pad8(N), seed=1)[:, :N]
+    out = K().gemm(layout, A, B, M, N, Kd, out_dtype=torch.float32)
+    a = A.float().t() if layout == 2 else A.float()
+    b = B.float().t() if layout == 0 else B.float()
+    close(out, a @ b, atol=1e-3 * math.sqrt(Kd), rtol=1e-3, what=f"gemm layout {layout} {shape}")
+
+
+def test_gemm_epilogue_bias_gelu_preact_residual_rowscale():
+    M, N, Kd = 300, 264, 128
+    A, W, res = rb(M, Kd), rb(N, Kd, seed=1, scale=0.1), rb(M, N, seed=2)
+    bias = torch.randn(N).cuda()
+    scale = torch.tensor([0.0, 1.25, 1.25], device="cuda")            # 3 samples of 100 rows, first one dropped
+    pre = torch.empty(M, N, dtype=bf16, device="cuda")
+    out = K().gemm(0, A, W, M, N, Kd, bias=bias, act=1, preact=pre, row_scale=scale, rows_per_group=100, residual=res)
+    z = A.float() @ W.float().t() + bias
+    close(pre, z, what="preact")
+    ref = F.gelu(z) * scale.repeat_interleave(100)[:, None] + res.float()
+    close(out, ref, what="gelu+rowscale+residual")
+    assert torch.equal(out[:100], res[:100])                           # dropped sample: identity branch, exactly
+
+
+def test_gemm_gelu_grad_and_colsum():
+    M, N, Kd = 260, 136, 96
+    dY, W, h = rb(M, Kd), rb(Kd, N, seed=1, scale=0.2), rb(M, N, seed=3)
+    cs = torch.zeros(N, device="cuda")
+    out = K().gemm(1, dY, W, M, N, Kd, gelu_in=h, colsum=cs)
+    hh = h.float().requires_grad_(True)
+    F.gelu(hh).sum().backward()
+    ref = (dY.float() @ W.float()) * hh.grad
+    close(out, ref, what="gelu' epilogue")
+    close(cs, ref.sum(0), atol=0.3, rtol=2e-2, what="colsum")
+
+
+def test_gemm_tn_splitk_rowsum_keep():
+    M, N, Kd = 200, 136, 3000                       # dW[M,N] = dY[K,M]^T X[K,N], K = token rows, 3 samples of 1000 rows
+    dY, X = rb(Kd, M), rb(Kd, N, seed=1)
+    keep = torch.tensor([1.25, 0.0, 1.25], device="cuda")
+    dW = torch.zeros(M, N, device="cuda")
+    db = torch.zeros(M, device="cuda")
+    K().gemm(2, dY, X, M, N, Kd, out=dW, accumulate=True, splits=5, k_keep=keep, k_rows_per_group=1000, alpha=1.25, rowsum_a=db)
+    m = (keep != 0).float().repeat_interleave(1000)[:, None].cpu()
+    ref = 1.25 * (dY.float().cpu() * m).t() @ X.float().cpu()
+    close(dW, ref, atol=0.3, rtol=1e-2, what="dW split-K + keep")
+    close(db, 1.25 * (dY.float().cpu() * m).sum(0), atol=0.3, rtol=1e-2, what="fused bias gradient")
+    K().gemm(2, dY, X, M, N, Kd, out=dW, accumulate=True, splits=2, k_keep=keep, k_rows_per_group=1000, alpha=1.25)
+    close(dW, 2 * ref, atol=0.6, rtol=1e-2, what="accumulation across calls")
+
+
+def test_gemm_ragged_vocab_tail():
+    M, V, Kd = 64, 1018, 128                         # V % 8 == 2 like 30522
+    ld = (V + 7) // 8 * 8
+    X, W = rb(M, Kd), rb(V, Kd, seed=1, scale=0.1)
+    bias = torch.randn(V).cuda()
+    buf = torch.full((M, ld), 7.0, dtype=bf16, device="cuda")
+    K().gemm(0, X, W, M, V, Kd, out=buf, bias=bias)
+    close(buf[:, :V], X.float() @ W.float().t() + bias, what="ragged N")
+    assert (buf[:, V:] == 7.0).all()                                     # padding columns untouched
+    buf[:, V:] = 0
+    dX = K().gemm(1, buf[:, :V], W, M, Kd, V)                             # K-contiguous operand with padded tail
+    close(dX, buf[:, :V].float() @ W.float(), atol=5e-2, what="ragged K")
+
+
+def test_gemm_dropout_mask_consistent_with_layernorm_bwd():
+    """The GEMM epilogue and the LN backward regenerate the SAME counter-based dropout mask."""
+    M, N, Kd, p, seed = 256, 128, 64, 0.3, 1234
+    ones = torch.ones(M, Kd, dtype=bf16, device="cuda")
+    W = (torch.ones(N, Kd) / Kd).to(bf16).cuda()
+    y = K().gemm(0, ones, W, M, N, Kd, dropout_p=p, seed=seed).float()        # = mask / (1-p)
+    mask = (y > 0).float()
+    assert abs(mask.mean().item() - (1 - p)) < 0.02
+    close(y, mask / (1 - p), atol=1e-2)
+    # LN backward "extra" output = dropout(dx): use gamma=1 and a dy that makes dx easy to compare
+    x = rb(M, N, seed=5)
+    dy = rb(M, N, seed=6)
+    g1 = torch.ones(N, device="cuda")
+    _, mean, rstd = K().layernorm_fwd(x, M, N, g1, torch.zeros(N, device="cuda"), 1e-5)
+    dg, db = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    dx2 = torch.empty(M, N, dtype=bf16, device="cuda")
+    cs = torch.zeros(N, device="cuda")
+    dx = K().layernorm_bwd(dy, x, M, N, g1, mean, rstd, dg, db, dx2=dx2, dropout_p=p, seed=seed, colsum=cs)
+    close(dx2, dx.float() * mask / (1 - p), atol=1e-2, what="masked LN-bwd output")
+    close(cs, (dx.float() * mask / (1 - p)).sum(0), atol=0.2, what="its column sums")
+
+
+# ---------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("C", [96, 128, 256, 512, 768, 1024, 2048, 3072])
+def test_layernorm_fwd_bwd(C):
+    rows = 333
+    x, dy, add = rb(rows, C), rb(rows, C, seed=1), rb(rows, C, seed=2)
+    gamma, beta = (1 + 0.1 * torch.randn(C)).cuda(), (0.1 * torch.randn(C)).cuda()
+    y, mean, rstd = K().layernorm_fwd(x, rows, C, gamma, beta, 1e-5)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    close(y, yr, what="LN fwd")
+    yr.backward(dy.float())
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = K().layernorm_bwd(dy, x, rows, C, gamma, mean, rstd, dg, db, add_in=add)
+    close(dx, xr.grad + add.float(), atol=3e-2, what="LN dx (+add)")
+    close(dg, gr.grad, atol=0.15, rtol=2e-2, what="dgamma")
+    close(db, br.grad, atol=0.15, rtol=2e-2, what="dbeta")
+
+
+def test_layernorm_patch_merge_gather():
+    BT, H, W, C0 = 3, 8, 6, 64
+    x = rb(BT * H * W, C0)
+    gamma, beta = (1 + 0.1 * torch.randn(4 * C0)).cuda(), (0.1 * torch.randn(4 * C0)).cuda()
+    rows = BT * H * W // 4
+    y, mean, rstd = K().layernorm_fwd(x, rows, 4 * C0, gamma, beta, 1e-5, gather=(H, W, C0))
+    xr = x.float().view(BT, H, W, C0).requires_grad_(True)
+    cat = torch.cat([xr[:, 0::2, 0::2], xr[:, 1::2, 0::2], xr[:, 0::2, 1::2], xr[:, 1::2, 1::2]], -1)   # video_swin.py:278-282
+    yr = F.layer_norm(cat, (4 * C0,), gamma, beta, 1e-5).reshape(rows, 4 * C0)
+    close(y, yr, what="gather LN fwd")
+    dy = rb(rows, 4 * C0, seed=3)
+    yr.backward(dy.float())
+    dg, db = torch.zeros(4 * C0, device="cuda"), torch.zeros(4 * C0, device="cuda")
+    dx = K().layernorm_bwd(dy, x, rows, 4 * C0, gamma, mean, rstd, dg, db, gather=(H, W, C0))
+    close(dx.view(BT, H, W, C0), xr.grad, atol=3e-2, what="gather LN scatter-back")
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def _win_ref(qkv, table, B, D, H, W, C, heads, win, shift, cfg):
+    """window attention of video_swin.py:145-170,218-239 on a (tokens, 3C) qkv tensor via the oracle helpers."""
+    from oracle import lavender_ref as R
+    N = win[0] * win[1] * win[2]
+    hd = C // heads
+    x = qkv.float().cpu().view(B, D, H, W, 3 * C)
+    if any(shift):
+        x = torch.roll(x, (-shift[0], -shift[1], -shift[2]), (1, 2, 3))
+    xw = R.partition(x, win)                                        # (Bw, N, 3C)
+    q, k, v = [t.reshape(-1, N, heads, hd).transpose(1, 2) for t in xw.split(C, -1)]
+    att = (q * hd ** -0.5) @ k.transpose(-1, -2)
+    idx = R.rel_pos_index(cfg)[:N, :N].reshape(-1)
+    att = att + table.float().cpu()[idx].reshape(N, N, heads).permute(2, 0, 1)[None]
+    if any(shift):
+        m = R.shift_mask(D, H, W, win, shift)
+        att = (att.view(B, -1, heads, N, N) + m[None, :, None]).view(-1, heads, N, N)
+    o = (att.softmax(-1) @ v).transpose(1, 2).reshape(-1, N, C)
+    o = R.unpartition(o, win, B, D, H, W)
+    if any(shift):
+        o = torch.roll(o, shift, (1, 2, 3))
+    return o.reshape(-1, C)
+
+
+@pytest.mark.parametrize("case", [
+    (2, 5, 14, 14, 64, 2, (5, 7, 7), (0, 3, 3)),        # N=245 shifted (persistent path)
+    (3, 5, 14, 14, 64, 2, (5, 7, 7), (0, 0, 0)),        # unshifted
+    (2, 4, 14, 7, 32, 1, (4, 7, 7), (0, 3, 0)),         # N=196, one axis clamped
+    (2, 1, 14, 14, 32, 1, (1, 7, 7), (0, 3, 3)),        # N=49 (image-text data, T=1)
+    (1, 16, 14, 14, 32, 1, (8, 7, 7), (4, 3, 3)),       # N=392 > 256: generic kernels, temporal shift
+])
+def test_window_attention_fwd_bwd(case):
+    B, D, H, W, C, heads, win, shift = case
+    cfg = (8, 7, 7)
+    M = B * D * H * W
+    qkv = rb(M, 3 * C)
+    table = (0.5 * torch.randn(15 * 13 * 13, heads)).cuda()
+    att = K().Attn(0, heads, 32, B=B, D=D, H=H, W=W, wd=win[0], wh=win[1], ww=win[2], sd=shift[0], sh=shift[1], sw=shift[2],
+                   cfg_wd=cfg[0], cfg_wh=cfg[1], cfg_ww=cfg[2], bias_table=table)
+    assert (win[0] * win[1] * win[2] <= 256) == hasattr(att, "comb")
+    lse = torch.empty(att.lse_elems(), device="cuda")
+    out = torch.empty(M, C, dtype=bf16, device="cuda")
+    att.fwd(qkv, out, lse)
+    qr = qkv.float().cpu().requires_grad_(True)
+    tr = table.float().cpu().requires_grad_(True)
+    ref = _win_ref(qr, tr, B, D, H, W, C, heads, win, shift, cfg)
+    close(out, ref, atol=2e-2, what=f"window fwd {case}")
+    dout = rb(M, C, seed=9)
+    ref.backward(dout.float().cpu())
+    dqkv = torch.empty_like(qkv)
+    dtab = torch.zeros_like(table)
+    att.bwd(qkv, out, dout, lse, dqkv, dtab)
+    close(dqkv, qr.grad, atol=4e-2, rtol=4e-2, what=f"window dqkv {case}")
+    rel = (dtab.cpu() - tr.grad).norm() / tr.grad.norm()
+    assert rel < 2e-2, f"bias-table gradient rel err {rel.item():.3g}"
+
+
+def _seq_ref(qkv, mask, n, L, heads):
+    Hd = heads * 64
+    q, k, v = [t.reshape(n, L, heads, 64).transpose(1, 2) for t in qkv.split(Hd, -1)]
+    s = q @ k.transpose(-1, -2) / 8.0 + (1.0 - mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    return (s.softmax(-1) @ v).transpose(1, 2).reshape(n * L, Hd)
+
+
+@pytest.mark.parametrize("n,L,heads", [(3, 282, 2), (2, 276, 1), (1, 757, 2), (5, 50, 1)])
+def test_sequence_attention_fwd_bwd(n, L, heads):
+    Hd = heads * 64
+    qkv = rb(n * L, 3 * Hd)
+    mask = torch.ones(n, L, dtype=torch.int32)
+    mask[0, L - 7:L - 1] = 0                                          # padded caption tokens
+    att = K().Attn(1, heads, 64, n_seq=n, L=L, key_mask=mask.cuda(), dropout_p=0.0, seed=0)
+    lse = torch.empty(att.lse_elems(), device="cuda")
+    out = torch.empty(n * L, Hd, dtype=bf16, device="cuda")
+    att.fwd(qkv, out, lse)
+    qr = qkv.float().cpu().requires_grad_(True)
+    ref = _seq_ref(qr, mask, n, L, heads)
+    close(out, ref, atol=2e-2, what="seq fwd")
+    dout = rb(n * L, Hd, seed=4)
+    ref.backward(dout.float().cpu())
+    dqkv = torch.empty_like(qkv)
+    att.bwd(qkv, out, dout, lse, dqkv, None)
+    close(dqkv, qr.grad, atol=4e-2, rtol=4e-2, what="seq dqkv")
+
+
+def test_sequence_attention_dropout_statistics():
+    n, L, heads, p = 4, 282, 2, 0.1
+    Hd = heads * 64
+    qkv = rb(n * L, 3 * Hd)
+    qkv[:, 2 * Hd:] = 1.0                                              # V = 1  ->  out = sum_k dropout(P)_k, mean 1
+    outs = []
+    for seed in (11, 11, 12):
+        att = K().Attn(1, heads, 64, n_seq=n, L=L, key_mask=None, dropout_p=p, seed=seed)
+        out = torch.empty(n * L, Hd, dtype=bf16, device="cuda")
+        att.fwd(qkv, out, torch.empty(att.lse_elems(), device="cuda"))
+        outs.append(out.float())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])     # pure function of the seed
+    assert abs(outs[0].mean().item() - 1.0) < 0.01 and outs[0].std().item() > 0.01
+
+
+# ---------------------------------------------------------------------------------------------- embeddings / gathers
+def test_patch_im2col_matches_conv3d():
+    from oracle import lavender_ref as R
+    B, T, H, W, E = 2, 3, 16, 24, 32
+    img = torch.randn(B, T, 3, H, W)
+    w, b = torch.randn(E, 3, 2, 4, 4) * 0.1, torch.randn(E) * 0.1
+    cols = K().patch_im2col(img.cuda(), B, T, H, W, True)
+    y = K().gemm(0, cols, w.view(E, 96).to(bf16).cuda(), cols.shape[0], E, 96, bias=b.cuda(), out_dtype=torch.float32)
+    x = F.pad(img.transpose(1, 2), (0, 0, 0, 0, 0, 1))
+    ref = F.conv3d(x, w, b, stride=(1, 4, 4)).permute(0, 2, 3, 4, 1).reshape(-1, E)
+    close(y, ref, atol=3e-2, what="patch embed")
+
+
+def test_text_embed_fwd_bwd():
+    n, X, Hd, V = 3, 32, 128, 500
+    ids = torch.randint(0, V, (n, X))
+    word, pos, typ = torch.randn(V, Hd) * 0.5, torch.randn(64, Hd) * 0.5, torch.randn(2, Hd) * 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(Hd), 0.1 * torch.randn(Hd)
+    c = lambda t: t.cuda().contiguous()
+    out, mean, rstd = K().text_embed_fwd(c(ids), n, X, Hd, c(word), c(pos), c(typ), c(gamma), c(beta), 1e-12, 0.0, 0)
+    ps = [t.clone().requires_grad_(True) for t in (word, pos, typ, gamma, beta)]
+    ref = F.layer_norm(ps[0][ids] + ps[1][:X] + ps[2][0], (Hd,), ps[3], ps[4], 1e-12)
+    close(out.view(n, X, Hd), ref, what="text embed fwd")
+    dout = rb(n * X, Hd, seed=2)
+    ref.backward(dout.float().cpu().view(n, X, Hd))
+    g = [torch.zeros_like(t).cuda() for t in (word, pos, typ, gamma, beta)]
+    K().text_embed_bwd(c(ids), dout, n, X, Hd, c(word), c(pos), c(typ), c(gamma), mean, rstd, 0.0, 0, g[0], g[1], g[2], g[3], g[4])
+    for got, p_, name in zip(g, ps, ("word", "pos", "type", "gamma", "beta")):
+        ref_g = p_.grad if name != "type" else torch.cat([p_.grad[:1], torch.zeros(1, Hd)])
+        close(got, ref_g, atol=0.05, rtol=2e-2, what=f"text embed d{name}")
+
+
+def test_video_embed_fwd_bwd():
+    B, T, hw, Hd = 2, 3, 4, 128
+    feat = rb(B * T * hw, Hd)
+    cls, pos, ln = torch.randn(1, 1, 1, Hd) * 0.5, torch.randn(1, 1, 1 + 9, Hd) * 0.5, torch.randn(1, 6, 1, Hd) * 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(Hd), 0.1 * torch.randn(Hd)
+    c = lambda t: t.cuda().contiguous()
+    Lv = T * (1 + hw)
+    out = torch.empty(B, Lv, Hd, dtype=bf16, device="cuda")
+    mean, rstd = K().video_embed_fwd(feat, B, T, hw, Hd, c(cls), c(pos), c(ln), c(gamma), c(beta), 1e-5, out, Lv)
+    ps = [t.clone().requires_grad_(True) for t in (cls, pos, ln, gamma, beta)]
+    fr = feat.float().cpu().view(B, T, hw, Hd).requires_grad_(True)
+    f = torch.cat([ps[0].expand(B, T, 1, Hd), fr], 2) + ps[1][:, :, :1 + hw] + ps[2][:, :T]     # model.py:69-83
+    ref = F.layer_norm(f, (Hd,), ps[3], ps[4], 1e-5).view(B, Lv, Hd)
+    close(out, ref, what="video embed fwd")
+    dout = rb(B, Lv, Hd, seed=3)
+    ref.backward(dout.float().cpu())
+    g = [torch.zeros_like(t).cuda() for t in (cls, pos, ln, gamma, beta)]
+    dfeat = torch.empty_like(feat)
+    K().video_embed_bwd(dout, Lv, feat, B, T, hw, Hd, c(cls), c(pos), c(ln), c(gamma), mean, rstd, dfeat, g[0], g[1], g[2], g[3], g[4])
+    close(dfeat.view(B, T, hw, Hd), fr.grad, atol=3e-2, what="video embed dfeat")
+    for got, p_, name in zip(g, ps, ("cls", "pos", "len", "gamma", "beta")):
+        close(got, p_.grad, atol=0.08, rtol=2e-2, what=f"video embed d{name}")
+
+
+def test_gather_rows_and_gather_sum():
+    src = rb(40, 64)
+    idx = torch.tensor([3, 3, 39, -1, 0, 7], dtype=torch.int32).cuda()
+    out = K().gather_rows(src, idx, 6, 64)
+    ref = src[[3, 3, 39, 0, 0, 7]].clone(); ref[3] = 0
+    assert torch.equal(out, ref)                                         # pure copy: bit-exact
+    start = torch.tensor([0, 2, 2, 5], dtype=torch.int32).cuda()
+    lst = torch.tensor([1, 4, 0, 2, 9], dtype=torch.int32).cuda()
+    s = K().gather_sum_rows(src, start, lst, 3, 64)
+    close(s[0], src[1].float() + src[4].float()); assert (s[1] == 0).all(); close(s[2], src[0].float() + src[2].float() + src[9].float())
+
+
+# ---------------------------------------------------------------------------------------------- loss / optimizer
+def test_cross_entropy_ignore_index():
+    rows, V = 37, 1018
+    ld = (V + 7) // 8 * 8
+    buf = torch.zeros(rows, ld, dtype=bf16, device="cuda")
+    buf[:, :V] = rb(rows, V, scale=2.0)
+    buf[:, V:] = 99.0                                                   # garbage in the padding must be ignored
+    labels = torch.randint(0, V, (rows,))
+    labels[::3] = -1
+    logits = buf[:, :V].float().cpu().requires_grad_(True)
+    ref = F.cross_entropy(logits, labels, ignore_index=-1)
+    ref.backward()
+    acc = torch.zeros(2, device="cuda")
+    K().cross_entropy(buf[:, :V], V, labels.cuda(), acc, 1.0 / int((labels >= 0).sum()), True)
+    assert acc[1].item() == int((labels >= 0).sum())
+    assert abs((acc[0] / acc[1]).item() - ref.item()) < 2e-3
+    close(buf[:, :V], logits.grad, atol=2e-4, rtol=2e-2, what="dlogits")
+    assert (buf[:, V:] == 0).all() and (buf[labels < 0] == 0).all()
+
+
+def test_fused_adamw_matches_torch():
+    n = 64 * 50
+    p0, g = torch.randn(n), torch.randn(n) * 3
+    grp = torch.randint(0, 4, (n // 64,), dtype=torch.uint8)
+    lr4, wd4 = [1e-3, 2e-3, 1e-3, 2e-3], [1e-2, 1e-2, 0.0, 0.0]
+    ps = [p0[(grp.repeat_interleave(64) == k)].clone().requires_grad_(True) for k in range(4)]
+    opt = torch.optim.AdamW([dict(params=[ps[k]], lr=lr4[k], weight_decay=wd4[k]) for k in range(4)], betas=(0.9, 0.98))
+    p, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    p16 = torch.empty(n, dtype=bf16, device="cuda")
+    for step in (1, 2, 3):
+        gs = g * step
+        for k in range(4):
+            ps[k].grad = gs[(grp.repeat_interleave(64) == k)].clone()
+        torch.nn.utils.clip_grad_norm_(ps, 1.0)                         # agent.py:246
+        opt.step()
+        sq = torch.zeros(1, device="cuda")
+        K().sumsq(gs.cuda(), n, sq)
+        K().adamw(n, p, gs.cuda(), m, v, p16, grp.cuda(), lr4, wd4, 0.9, 0.98, 1e-8, step, sq, 1.0, 1.0)
+    got = p.cpu()
+    for k in range(4):
+        np.testing.assert_allclose(got[(grp.repeat_interleave(64) == k)].numpy(), ps[k].detach().numpy(), rtol=2e-5, atol=2e-6)
+    close(p16, got, atol=1e-2, rtol=1e-2)

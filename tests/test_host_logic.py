@@ -1,0 +1,159 @@
+"""CPU: host-side logic of the product (no kernels are launched): integer paths bit-exact against the golden
+vectors captured from the reference, optimizer grouping / LR schedule, arena ordering, window geometry tables,
+and that the C-ABI library loads and exports every symbol declared in include/lavender_hip.h."""
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def test_library_exports_every_declared_symbol():
+    from lavender_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "lavender_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(lav_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(_lib.lib, name), f"{name} declared in lavender_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.lib.lav_abi_version() == 1
+
+
+def test_argument_errors_are_reported_not_thrown():
+    from lavender_amd import _lib
+    rc = _lib.lib.lav_gemm_bf16(None, 7, 1, 1, 1, None, 8, None, 8, None, 8, None, 1)
+    assert rc < 0 and b"layout" in _lib.lib.lav_last_error()
+
+
+@pytest.mark.parametrize("seed", [88, 0, 1])
+@pytest.mark.parametrize("BX", [(2, 33), (8, 32), (32, 32)])
+def test_masking_bit_exact(golden_dir, seed, BX):
+    from lavender_amd.pretrain_mlm import masking
+    g = _g(golden_dir, "ints")
+    B, X = BX
+    tin = torch.from_numpy(g[f"masking_s{seed}_B{B}_X{X}_in"]).clone()
+    torch.manual_seed(seed)
+    out = masking(tin, (tin != 0).long(), (101, 102, 0, 103))
+    assert (out["txt"].numpy() == g[f"masking_s{seed}_B{B}_X{X}_txt"]).all()
+    assert (out["ans_mtm"].numpy() == g[f"masking_s{seed}_B{B}_X{X}_ans"]).all()
+
+
+def test_vtm_pairs_known_answer():
+    from lavender_amd.pretrain_mlm import vtm_pairs
+    np.random.seed(88)
+    vi, ti, tr = vtm_pairs(4, 4)
+    assert ti.reshape(4, 4)[:, 1:].tolist() == [[2, 3, 1], [3, 0, 2], [3, 1, 0], [0, 1, 2]]
+    assert vi.tolist() == [i for i in range(4) for _ in range(4)]
+    assert tr.reshape(4, 4)[:, 0].all() and not tr.reshape(4, 4)[:, 1:].any()
+
+
+def test_param_groups_match_reference(golden_dir):
+    from lavender_amd.arena import param_group_of
+    g = _g(golden_dir, "agent")
+    for i in range(4):
+        for n in g[f"group{i}"].tolist():
+            assert param_group_of(n) == i, n
+
+
+def test_lr_schedule_matches_reference(golden_dir):
+    from lavender_amd.agent import WarmupLinearLR
+
+    class Opt:
+        param_groups = [dict(lr=2e-5)]
+    o = Opt()
+    sch = WarmupLinearLR(o, 100)
+    lrs = []
+    for _ in range(110):
+        lrs.append(o.param_groups[0]["lr"])
+        sch.step()
+    np.testing.assert_allclose(lrs, _g(golden_dir, "ints")["lr_max_iter100_lr2e-5"], rtol=1e-12)
+    assert lrs[0] == 1e-8                                         # first optimizer step runs at the min_lr floor
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    from tests.helpers import Tok, make_args
+    from lavender_amd import LAVENDER_Pretrain_MLM
+    t = _g(golden_dir, "tiny2l_b2")
+    m = LAVENDER_Pretrain_MLM(make_args("tiny", "b2l", 2), Tok())
+    ours = {k: str(tuple(v.shape)) for k, v in m.state_dict().items()}
+    ref = dict(zip(t["keys"].tolist(), t["shapes"].tolist()))
+    assert ours == ref
+    assert len(list(m.named_parameters())) == 221            # decoder.bias tied to predictions.bias
+
+
+def test_arena_order_groups_qkv():
+    from lavender_amd.arena import _order
+    names = []
+    for n in ("query", "key", "value"):
+        names += [f"trsfr.layer.0.attention.self.{n}.weight", f"trsfr.layer.0.attention.self.{n}.bias"]
+    named = [("a.weight", 0)] + [(n, 0) for n in names] + [("b.bias", 0)]
+    got = [n for n, _ in _order(named)]
+    pre = "trsfr.layer.0.attention.self."
+    assert got == ["a.weight"] + [pre + f"{n}.weight" for n in ("query", "key", "value")] + \
+        [pre + f"{n}.bias" for n in ("query", "key", "value")] + ["b.bias"]
+
+
+def test_get_window_size(golden_dir):
+    from lavender_amd.video_swin import get_window_size
+    g = _g(golden_dir, "ints")
+    for c, o in zip(g["gws_in"], g["gws_out"]):
+        w, s = get_window_size(tuple(c[0]), tuple(c[1]), tuple(c[2]))
+        assert (list(w), list(s)) == (list(o[0]), list(o[1]))
+
+
+@pytest.mark.parametrize("win", [(8, 7, 7), (8, 12, 12)])
+def test_relative_position_index(golden_dir, win):
+    from lavender_amd.video_swin import relative_position_index
+    g = _g(golden_dir, "ints")
+    idx = relative_position_index(win).numpy().astype(np.int64)
+    assert hashlib.sha256(idx.tobytes()).hexdigest() == str(g["rpi_" + "x".join(map(str, win)) + "_sha"])
+
+
+@pytest.mark.parametrize("case", [(5, 56, 56, (5, 7, 7), (0, 3, 3)), (5, 14, 14, (5, 7, 7), (0, 3, 3)),
+                                  (4, 14, 14, (2, 7, 7), (1, 3, 3)), (5, 21, 21, (5, 7, 7), (0, 3, 3)),
+                                  (5, 7, 7, (5, 7, 7), (0, 0, 0))])
+def test_window_tables_reproduce_roll_partition_and_mask(golden_dir, case):
+    """tok table == roll(-shift) + window_partition of a token-index tensor (video_swin.py:82-86,218-227);
+    type/region tables reproduce compute_mask (video_swin.py:290-305) bit-exactly."""
+    from lavender_amd.hip import window_tables
+    from oracle import lavender_ref as R
+    D, H, W, win, sh = case
+    N = win[0] * win[1] * win[2]
+    t = window_tables(torch.device("cpu"), D, H, W, win, sh)
+    ids = torch.arange(D * H * W, dtype=torch.float32).view(1, D, H, W, 1)
+    rolled = torch.roll(ids, (-sh[0], -sh[1], -sh[2]), (1, 2, 3)) if any(sh) else ids
+    ref = R.partition(rolled, win).squeeze(-1).long()
+    assert (t["tok"][:, :N].long() == ref).all() and (t["tok"][:, N:] == -1).all()
+    if any(sh):
+        reg = t["region"].long()[t["wtype"].long()][:, :N]
+        mine = torch.where(reg[:, None, :] != reg[:, :, None], -100.0, 0.0)
+        assert torch.equal(mine, R.shift_mask(D, H, W, win, sh))
+        g = _g(golden_dir, "ints")
+        tag = f"mask_{D}_{H}_{W}_" + "x".join(map(str, win)) + "_" + "x".join(map(str, sh)) + "_sha"
+        if tag in g.files:
+            assert hashlib.sha256(np.packbits((mine != 0).numpy()).tobytes()).hexdigest() == str(g[tag])
+
+
+def test_no_cpu_path():
+    from tests.helpers import Tok, make_args
+    from lavender_amd import LAVENDER_Pretrain_MLM
+    m = LAVENDER_Pretrain_MLM(make_args("micro", "micro", 2), Tok())
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m.arena()
+
+
+def test_args_json_overlay(tmp_path):
+    import json
+    from lavender_amd.args import parse_with_config
+    cfg = tmp_path / "a.json"
+    cfg.write_text(json.dumps({"size_batch": 24, "size_frame": 4, "type": "pretrain", "lr": 2e-5}))
+    a = parse_with_config(["--config", str(cfg), "--size_batch", "32"])
+    assert a.size_batch == 32 and a.size_frame == 4 and a.type == "pretrain" and a.lr == 2e-5   # CLI > JSON > default
