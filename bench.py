@@ -190,32 +190,32 @@ def main():
     loss_vals = {k: float(v) for k, v in last.items()}
 
     # ---- dominant-kernel roofline: every forward (NT) GEMM launch of one more step, HIP events on its stream ----
+    # every rank runs the sampling step (it contains the gradient all-reduce); only rank 0 instruments and reports
     roof = None
-    if rank == 0:
-        rec = []
-        orig = K.gemm
+    rec = []
+    orig = K.gemm
 
-        def timed(layout, A, Bm, M, N, Kd, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = orig(layout, A, Bm, M, N, Kd, **kw)
-            e1.record()
-            rec.append((layout, 2.0 * M * N * Kd, e0, e1))
-            return r
+    def timed(layout, A, Bm, M, N, Kd, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(layout, A, Bm, M, N, Kd, **kw)
+        e1.record()
+        rec.append((layout, 2.0 * M * N * Kd, e0, e1))
+        return r
+    if rank == 0:
         K.gemm = timed
-        import lavender_amd.engine as ENG
-        ENG.K.gemm = timed
-        run_step(0)
-        torch.cuda.synchronize()
-        K.gemm = orig
-        ENG.K.gemm = orig
+    run_step(0)
+    torch.cuda.synchronize()
+    K.gemm = orig
+    if rank == 0:
         by = {}
         for layout, fl, e0, e1 in rec:
             d = by.setdefault(layout, [0, 0.0, 0.0])
             d[0] += 1; d[1] += fl; d[2] += e0.elapsed_time(e1) * 1e-3
         n, fl, tm = by[0]
         tot_fl = sum(v[1] for v in by.values()); tot_t = sum(v[2] for v in by.values())
-        roof = {"bound": "mfma", "kernel": "gemm_kernel<NT> (lav_gemm_bf16 layout 0)", "achieved": round(fl / tm / 1e12, 2),
+        roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T GEMMs: gemm_huge/big/gemm_kernel<NT>)",
+                "achieved": round(fl / tm / 1e12, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tm / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
                 "launches_per_step": n, "avg_launch_us": round(tm / n * 1e6, 2), "avg_launch_gflop": round(fl / n / 1e9, 3),
                 "all_gemm_layouts": {"launches": sum(v[0] for v in by.values()), "tflops": round(tot_fl / tot_t / 1e12, 2),

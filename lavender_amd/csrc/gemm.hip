@@ -10,6 +10,7 @@
 // epilogue (bias / GELU / dropout / drop-path scale / residual / column sums) runs on 8-wide row
 // chunks with 16-byte global accesses.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/lavender_hip.h"
 
 #define BM 128
@@ -34,10 +35,25 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_base, int off) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_base + off));
 }
 
+// LDS images of one operand tile (16 KB):
+//   K-contiguous operand : [128 rows][64 k] bf16, 128-byte rows, 16-byte slot s stored at s ^ (row & 7)
+//                          -> ds_read_b128 fragment reads are bank-conflict-free
+//   contraction-strided  : [64 k][128 n] bf16, 256-byte rows, 32-byte chunk c stored at c ^ skey(k)
+//                          -> the four k-rows x 32 B that one ds_read_b64_tr_b16 lane group gathers, and the two
+//                             groups of a 32-lane half, land on 8 distinct chunks = all 64 banks
+// Both images are "row-linear up to a permutation inside the row", so a tile can be filled either through
+// registers (edge tiles: zero fill, drop-path row skipping) or by global_load_lds (1 KB per wave-instruction,
+// LDS address = base + lane*16) with the inverse permutation applied to the per-lane SOURCE address.
+__device__ __forceinline__ int skey(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
 // ---- global -> registers (one 128x64 or 64x128 operand tile = 4 x 16 B per thread) -------------
+// keep-mask of one k-tile (drop-path row skipping, TN only): a 64-row tile spans at most two samples
+// (rows_per_group >= 64), so the mask is "rows below kb use keep0, the rest keep1" -- scalars, no per-load division.
+struct KeepInfo { int kb; bool k0, k1; };
+
 template <bool KCONTIG>
 __device__ __forceinline__ void tile_load(uint4 (&r)[4], const bf16_t* __restrict__ P, long ld, int o0, int O,
-                                          int k0, int kend, int tid, const float* keep, int keep_rpg) {
+                                          int k0, int kend, int tid, const KeepInfo& ki) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int c = tid + NT_ * j;
@@ -49,8 +65,7 @@ __device__ __forceinline__ void tile_load(uint4 (&r)[4], const bf16_t* __restric
         } else {
             int krow = c >> 4, n8 = c & 15;
             int gk = k0 + krow, go = o0 + n8 * 8;
-            bool ok = gk < kend && go < O;
-            if (ok && keep) ok = keep[gk / keep_rpg] != 0.f;
+            bool ok = gk < kend && go < O && (gk < ki.kb ? ki.k0 : ki.k1);
             if (ok) v = *(const uint4*)(P + (long)gk * ld + go);
         }
         r[j] = v;
@@ -68,11 +83,33 @@ __device__ __forceinline__ void tile_store(const uint4 (&r)[4], char* lds, int t
             off = row * 128 + ((slot ^ (row & 7)) << 4);
         } else {
             int krow = c >> 4, n8 = c & 15;
-            int sub = n8 >> 1, half = n8 & 1, ks = krow >> 5, kk = krow & 31;
-            int pos = (kk & 3) | (((kk >> 3) & 3) << 2) | (((kk >> 2) & 1) << 4);
-            off = sub * 2048 + ks * 1024 + ((pos ^ (sub & 3)) << 5) + half * 16;
+            off = krow * 256 + (((n8 >> 1) ^ skey(krow)) << 5) + (n8 & 1) * 16;
         }
         *(uint4*)(lds + off) = r[j];
+    }
+}
+
+// ---- global -> LDS without registers: 4 wave-instructions per wave per operand tile ----------------
+// Only for full k-tiles; rows / columns past the operand's extent are clamped to a valid address (they only feed
+// output rows / columns that the epilogue masks).
+template <bool KCONTIG>
+__device__ __forceinline__ void tile_glds(char* lds, const bf16_t* __restrict__ P, long ld, int o0, int O, int k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = wave * 4 + i;
+        const bf16_t* src;
+        if (KCONTIG) {
+            int row = min(o0 + t * 8 + (lane >> 3), O - 1);
+            int slot = (lane & 7) ^ ((lane >> 3) & 7);
+            src = P + (long)row * ld + k0 + slot * 8;
+        } else {
+            int krow = t * 4 + (lane >> 4);
+            int ch = ((lane & 15) >> 1) ^ skey(krow);
+            int col = min(o0 + ch * 16 + (lane & 1) * 8, ((O + 7) & ~7) - 8);
+            src = P + (long)(k0 + krow) * ld + col;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + t * 1024), 16, 0, 0);
     }
 }
 
@@ -85,143 +122,24 @@ __device__ __forceinline__ bf16x8 frag_read(const char* lds, int t16, int ks, in
         return *(const bf16x8*)(lds + row * 128 + ((slot ^ (row & 7)) << 4));
     } else {
         int i = lane & 15, g = lane >> 4, r = i >> 2, c = i & 3;
-        int base = t16 * 2048 + ks * 1024 + c * 8;
-        int sw = t16 & 3;
-        s16x4 lo = tr_read(lds, base + (((r + 4 * g) ^ sw) << 5));
-        s16x4 hi = tr_read(lds, base + (((16 + r + 4 * g) ^ sw) << 5));
+        int k = ks * 32 + 8 * g + r;                       // rows k..k+3 via lanes r=0..3 of the group; second read k+4
+        int ch = (t16 ^ skey(k)) << 5;                     // skey(k) == skey(k + 4)
+        s16x4 lo = tr_read(lds, k * 256 + ch + c * 8);
+        s16x4 hi = tr_read(lds, (k + 4) * 256 + ch + c * 8);
         union { struct { s16x4 a, b; } s; bf16x8 v; } u;
         u.s.a = lo; u.s.b = hi;
         return u.v;
     }
 }
 
-// KG = number of 4-wave groups per block.  KG == 2 (weight gradients): the two groups walk alternate k-tiles of
-// the SAME output tile with private LDS stages and merge their accumulators through LDS -- twice the waves per
-// CU without doubling the number of fp32-atomic output tiles (the epilogue atomics are what caps split-K).
-template <bool AK, bool BK, int KG>
-__global__ __launch_bounds__(NT_ * KG) void gemm_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem_all[];
-    const int grp = KG == 1 ? 0 : (threadIdx.x >> 8);
-    char* smem = smem_all + grp * 65536;
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // XCD-aware bijective remap: each XCD (block b -> XCD b % 8) walks a contiguous run of tiles, n fastest
-    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
-    const int kbeg = blockIdx.z * g.k_per_split;
-    const int kend = min(g.K, kbeg + g.k_per_split);
-    const int nk = (kend - kbeg + BKT - 1) / BKT;
-
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // TN only: bias gradient = sum over the contraction of A's columns, computed on the matrix cores against a
-    // ones fragment by the wn==0 waves of the n0==0 blocks (every column of the product equals the row sum)
-    const bool do_rowsum = !AK && g.e.rowsum_a != nullptr && n0 == 0 && wn == 0;
-    f32x4 acc1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 ones;
-    {
-        union { uint4 u; bf16x8 b; } o; o.u = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); ones = o.b;
-    }
-
-    uint4 ra[4], rb[4];
-    const float* keep = g.e.k_keep;
-    const int nit = (nk + KG - 1) / KG;                    // iterations per group (tiles kt = it*KG + grp; overrun tiles read as zeros)
-    if (nk > 0) {
-        tile_load<AK>(ra, g.A, g.lda, m0, g.M, kbeg + grp * BKT, kend, tid, keep, g.e.k_rows_per_group);
-        tile_load<BK>(rb, g.B, g.ldb, n0, g.N, kbeg + grp * BKT, kend, tid, keep, g.e.k_rows_per_group);
-        tile_store<AK>(ra, smem, tid);
-        tile_store<BK>(rb, smem + 16384, tid);
-    }
-    __syncthreads();
-    for (int it = 0; it < nit; ++it) {
-        const int cur = it & 1;
-        char* la = smem + cur * 32768;
-        char* lb = la + 16384;
-        if (it + 1 < nit) {
-            const int k0n = kbeg + ((it + 1) * KG + grp) * BKT;
-            tile_load<AK>(ra, g.A, g.lda, m0, g.M, k0n, kend, tid, keep, g.e.k_rows_per_group);
-            tile_load<BK>(rb, g.B, g.ldb, n0, g.N, k0n, kend, tid, keep, g.e.k_rows_per_group);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = frag_read<AK>(la, wm * 4 + i, ks, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = frag_read<BK>(lb, wn * 4 + j, ks, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            if (!AK && do_rowsum) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, acc1[i], 0, 0, 0);
-            }
-        }
-        if (it + 1 < nit) {
-            tile_store<AK>(ra, smem + (cur ^ 1) * 32768, tid);
-            tile_store<BK>(rb, smem + (cur ^ 1) * 32768 + 16384, tid);
-        }
-        __syncthreads();
-    }
-
-    if (!AK && do_rowsum && (lane & 15) == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-                if (row < g.M) atomicAdd(g.e.rowsum_a + row, acc1[i][r] * g.e.alpha);
-            }
-    }
-    // ---- stage the accumulator tile through LDS (fp32, row stride 132 floats) ----------------------
-    float* cl = (float*)smem_all;
-    if (KG == 1 || grp == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-                    int col = wn * 64 + j * 16 + (lane & 15);
-                    cl[row * CSTRIDE + col] = acc[i][j][r];
-                }
-    }
-    __syncthreads();
-    if (KG == 2) {
-        if (grp == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-                        int col = wn * 64 + j * 16 + (lane & 15);
-                        cl[row * CSTRIDE + col] += acc[i][j][r];
-                    }
-        }
-        __syncthreads();
-    }
-
+// ---- fused epilogue over the fp32 accumulator tile staged in LDS (row stride CSTRIDE): all NTHR threads, 8-wide
+// row chunks, 16-byte global accesses.  Order: alpha, bias, [preact], GELU, GELU', dropout, drop-path scale,
+// residual, [column sums], store.
+template <int ROWS, int NTHR>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int m0, int n0) {
     const lav_gemm_epilogue& e = g.e;
-    const int cc = tid & 15;
+    const int etid = threadIdx.x;
+    const int cc = etid & 15;
     const int gcol = n0 + cc * 8;
     float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -232,10 +150,9 @@ __global__ __launch_bounds__(NT_ * KG) void gemm_kernel(GemmArgs g) {
             if (x < ncols) bias[x] = e.bias[gcol + x];
     }
     const bool full = ncols == 8;
-    const int etid = threadIdx.x;                           // all KG*256 threads share the epilogue
 #pragma unroll 1
-    for (int j = 0; j < 8 / KG; ++j) {
-        const int row = (etid >> 4) + 16 * KG * j;
+    for (int j = 0; j < ROWS / (NTHR / 16); ++j) {
+        const int row = (etid >> 4) + (NTHR / 16) * j;
         const int grow = m0 + row;
         if (grow >= g.M || ncols <= 0) continue;
         float v[8];
@@ -298,18 +215,432 @@ __global__ __launch_bounds__(NT_ * KG) void gemm_kernel(GemmArgs g) {
     }
     if (e.colsum) {
         __syncthreads();
-        float* red = (float*)smem_all;                   // [16*KG][128]
+        float* red = cl;                                  // [NTHR/16][128]
 #pragma unroll
         for (int x = 0; x < 8; ++x) red[(etid >> 4) * 128 + cc * 8 + x] = csum[x];
         __syncthreads();
         if (etid < 128 && n0 + etid < g.N) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16 * KG; ++r) s += red[r * 128 + etid];
+            for (int r = 0; r < NTHR / 16; ++r) s += red[r * 128 + etid];
             atomicAdd(e.colsum + n0 + etid, s);
         }
     }
 }
+
+// KG = number of 4-wave groups per block.  KG == 2 (weight gradients): the two groups walk alternate k-tiles of
+// the SAME output tile with private LDS stages and merge their accumulators through LDS -- twice the waves per
+// CU without doubling the number of fp32-atomic output tiles (the epilogue atomics are what caps split-K).
+template <bool AK, bool BK, int KG>
+__global__ __launch_bounds__(NT_ * KG) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int grp = KG == 1 ? 0 : (threadIdx.x >> 8);
+    char* smem = smem_all + grp * 65536;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap: each XCD (block b -> XCD b % 8) walks a contiguous run of tiles, n fastest
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nk = (kend - kbeg + BKT - 1) / BKT;
+
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // TN only: bias gradient = sum over the contraction of A's columns, computed on the matrix cores against a
+    // ones fragment by the wn==0 waves of the n0==0 blocks (every column of the product equals the row sum)
+    const bool do_rowsum = !AK && g.e.rowsum_a != nullptr && n0 == 0 && wn == 0;
+    f32x4 acc1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+    {
+        union { uint4 u; bf16x8 b; } o; o.u = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); ones = o.b;
+    }
+
+    uint4 ra[4], rb[4];
+    const float* keep = g.e.k_keep;
+    const int nit = (nk + KG - 1) / KG;                    // iterations per group (tiles kt = it*KG + grp; overrun tiles read as zeros)
+    // per k-tile mode: 0 = every row dropped (skip loads and MFMAs), 1 = full tile, no masking: HBM -> LDS directly,
+    // 2 = through registers (K tail, or a tile that straddles a kept and a dropped sample)
+    KeepInfo ki; ki.kb = 0x7fffffff; ki.k0 = ki.k1 = true;
+    auto tile_mode = [&](int k0, KeepInfo& o) {
+        o.kb = 0x7fffffff; o.k0 = o.k1 = true;
+        if (k0 >= kend) return 0;
+        if (keep) {
+            const int s0 = k0 / g.e.k_rows_per_group;
+            o.kb = (s0 + 1) * g.e.k_rows_per_group;
+            o.k0 = keep[s0] != 0.f;
+            o.k1 = o.kb < min(k0 + BKT, kend) ? keep[s0 + 1] != 0.f : o.k0;
+            if (!o.k0 && !o.k1) return 0;
+            if (!o.k0 || !o.k1) return 2;
+        }
+        return k0 + BKT <= kend ? 1 : 2;
+    };
+    int mode_cur = 0;
+    if (nk > 0) {
+        const int k0 = __builtin_amdgcn_readfirstlane(kbeg + grp * BKT);
+        mode_cur = tile_mode(k0, ki);
+        if (mode_cur == 1) {
+            tile_glds<AK>(smem, g.A, g.lda, m0, g.M, k0, wave, lane);
+            tile_glds<BK>(smem + 16384, g.B, g.ldb, n0, g.N, k0, wave, lane);
+        } else if (mode_cur == 2) {
+            tile_load<AK>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, ki);
+            tile_load<BK>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, ki);
+            tile_store<AK>(ra, smem, tid);
+            tile_store<BK>(rb, smem + 16384, tid);
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+        const int cur = it & 1;
+        char* la = smem + cur * 32768;
+        char* lb = la + 16384;
+        const int k0n = __builtin_amdgcn_readfirstlane(kbeg + ((it + 1) * KG + grp) * BKT);
+        const int mode_next = it + 1 < nit ? tile_mode(k0n, ki) : 0;
+        if (mode_next == 1) {
+            tile_glds<AK>(smem + (cur ^ 1) * 32768, g.A, g.lda, m0, g.M, k0n, wave, lane);
+            tile_glds<BK>(smem + (cur ^ 1) * 32768 + 16384, g.B, g.ldb, n0, g.N, k0n, wave, lane);
+        } else if (mode_next == 2) {
+            tile_load<AK>(ra, g.A, g.lda, m0, g.M, k0n, kend, tid, ki);
+            tile_load<BK>(rb, g.B, g.ldb, n0, g.N, k0n, kend, tid, ki);
+        }
+        if (mode_cur != 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = frag_read<AK>(la, wm * 4 + i, ks, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = frag_read<BK>(lb, wn * 4 + j, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (!AK && do_rowsum) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, acc1[i], 0, 0, 0);
+                }
+            }
+        }
+        if (mode_next == 2) {
+            tile_store<AK>(ra, smem + (cur ^ 1) * 32768, tid);
+            tile_store<BK>(rb, smem + (cur ^ 1) * 32768 + 16384, tid);
+        }
+        mode_cur = mode_next;
+        __syncthreads();
+    }
+
+    if (!AK && do_rowsum && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (row < g.M) atomicAdd(g.e.rowsum_a + row, acc1[i][r] * g.e.alpha);
+            }
+    }
+    // ---- stage the accumulator tile through LDS (fp32, row stride 132 floats) ----------------------
+    float* cl = (float*)smem_all;
+    if (KG == 1 || grp == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                    int col = wn * 64 + j * 16 + (lane & 15);
+                    cl[row * CSTRIDE + col] = acc[i][j][r];
+                }
+    }
+    __syncthreads();
+    if (KG == 2) {
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                        int col = wn * 64 + j * 16 + (lane & 15);
+                        cl[row * CSTRIDE + col] += acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+    }
+
+    gemm_epilogue<BM, NT_ * KG>(g, cl, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Large-M variant for the forward / input-gradient layouts (A K-contiguous): 256x128x64 tile, 512 threads = 8 waves
+// (4 x 2, 64x64 each), THREE LDS stages filled only by global_load_lds.  Loads for k-tile t+2 are issued before the
+// MFMAs of tile t and the single barrier per tile waits with a COUNTED vmcnt (the newest tile stays in flight), so
+// HBM / L2 latency is covered by two tiles of compute instead of sitting behind every barrier.
+// Requires K % 64 == 0 (true for every Swin-B / BERT shape; the 128x128 kernel handles the rest).
+// ------------------------------------------------------------------------------------------------------
+#define BIG_BM 256
+#define BIG_STAGE 49152
+#define BIG_LDS (3 * BIG_STAGE)
+
+template <bool KCONTIG, int INSTR_PER_WAVE>
+__device__ __forceinline__ void big_glds(char* lds, const bf16_t* __restrict__ P, long ld, int o0, int O, int k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < INSTR_PER_WAVE; ++i) {
+        const int t = wave * INSTR_PER_WAVE + i;
+        const bf16_t* src;
+        if (KCONTIG) {
+            int row = min(o0 + t * 8 + (lane >> 3), O - 1);
+            int slot = (lane & 7) ^ ((lane >> 3) & 7);
+            src = P + (long)row * ld + k0 + slot * 8;
+        } else {
+            int krow = t * 4 + (lane >> 4);
+            int ch = ((lane & 15) >> 1) ^ skey(krow);
+            int col = min(o0 + ch * 16 + (lane & 1) * 8, ((O + 7) & ~7) - 8);
+            src = P + (long)(k0 + krow) * ld + col;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + t * 1024), 16, 0, 0);
+    }
+}
+
+template <bool BKC>
+__global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BIG_BM - 1) / BIG_BM;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / tiles_n) * BIG_BM, n0 = (bid % tiles_n) * BN;
+    const int nk = g.K / BKT;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int kt) {
+        char* st = smem + (kt % 3) * BIG_STAGE;
+        big_glds<true, 4>(st, g.A, g.lda, m0, g.M, kt * BKT, wave, lane);            // 256 rows x 128 B = 32 instr
+        big_glds<BKC, 2>(st + 32768, g.B, g.ldb, n0, g.N, kt * BKT, wave, lane);     // 16 KB = 16 instr
+    };
+    issue(0);
+    if (nk > 1) {
+        issue(1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* la = smem + (kt % 3) * BIG_STAGE;
+        const char* lb = la + 32768;
+        const bool more = kt + 2 < nk;
+        if (more) issue(kt + 2);
+        {
+            // all 16 fragment reads of the k-tile are issued up front; the MFMAs of k-step 0 start as soon as ITS
+            // eight fragments have landed (counted lgkmcnt) and cover the flight of k-step 1's fragments
+            bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa0[i] = frag_read<true>(la, wm * 4 + i, 0, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb0[j] = frag_read<BKC>(lb, wn * 4 + j, 0, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa1[i] = frag_read<true>(la, wm * 4 + i, 1, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb1[j] = frag_read<BKC>(lb, wn * 4 + j, 1, lane);
+            __builtin_amdgcn_sched_barrier(0);            // keep the 16 reads above the MFMAs (hipcc otherwise sinks them)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
+        }
+        // tile kt+1 must have landed (6 wave-instructions per tile per wave; keep tile kt+2 in flight)
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    float* cl = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                int col = wn * 64 + j * 16 + (lane & 15);
+                cl[row * CSTRIDE + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    gemm_epilogue<BIG_BM, 512>(g, cl, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 256x256x64 variant (N a multiple of 256, large M): 8 waves as 2 x 4, each 128x64 = 8x4 MFMA tiles (128
+// accumulator registers).  PMC on the 256x128 kernel (8192^3): MFMA busy 41 %, waves 29 % in s_waitcnt/barrier --
+// the per-CU L2->LDS stream (48 KB per 2*256*128*64 flop, 85 flop/B) is what paces it; the square tile moves 64 KB
+// per 2x the flops (128 flop/B) and needs only two LDS stages because one tile of MFMAs (2176 cycles per SIMD)
+// already covers the load latency.  The accumulator tile is handed to the epilogue in two 128-column halves.
+// ------------------------------------------------------------------------------------------------------
+#define HUGE_STAGE 65536
+#define HUGE_LDS (BIG_BM * CSTRIDE * 4 > 2 * HUGE_STAGE ? BIG_BM * CSTRIDE * 4 : 2 * HUGE_STAGE)
+
+__device__ __forceinline__ void huge_glds_strided(char* lds, const bf16_t* __restrict__ P, long ld, int o0, int O, int k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                          // [64 k][256 n] bf16, 512-byte rows, 2 rows per wave-instruction
+        const int t = wave * 4 + i;
+        const int krow = t * 2 + (lane >> 5);
+        const int ch = ((lane & 31) >> 1) ^ skey(krow);
+        const int col = min(o0 + ch * 16 + (lane & 1) * 8, ((O + 7) & ~7) - 8);
+        const bf16_t* src = P + (long)(k0 + krow) * ld + col;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + t * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8 huge_frag_strided(const char* lds, int t16, int ks, int lane) {
+    const int i = lane & 15, g = lane >> 4, r = i >> 2, c = i & 3;
+    const int k = ks * 32 + 8 * g + r;
+    const int ch = (t16 ^ skey(k)) << 5;
+    s16x4 lo = tr_read(lds, k * 512 + ch + c * 8);
+    s16x4 hi = tr_read(lds, (k + 4) * 512 + ch + c * 8);
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles_n = g.N / 256, tiles_m = (g.M + BIG_BM - 1) / BIG_BM;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / tiles_n) * BIG_BM, n0 = (bid % tiles_n) * 256;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nk = (kend - kbeg) / BKT;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // TN: bias gradient (row sums of A^T) on the matrix cores against a ones fragment, wn == 0 waves of the n0 == 0 blocks
+    const bool do_rowsum = !AKC && g.e.rowsum_a != nullptr && n0 == 0 && wn == 0;
+    f32x4 acc1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+    {
+        union { uint4 u; bf16x8 b; } o; o.u = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); ones = o.b;
+    }
+
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 1) * HUGE_STAGE;
+        const int k0 = kbeg + kt * BKT;
+        if (AKC) big_glds<true, 4>(st, g.A, g.lda, m0, g.M, k0, wave, lane);
+        else huge_glds_strided(st, g.A, g.lda, m0, g.M, k0, wave, lane);
+        if (BKC) big_glds<true, 4>(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);
+        else huge_glds_strided(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);
+    };
+    if (nk > 0) issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* la = smem + (kt & 1) * HUGE_STAGE;
+        const char* lb = la + 32768;
+        if (kt + 1 < nk) issue(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[8], fb[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = AKC ? frag_read<true>(la, wm * 8 + i, ks, lane) : huge_frag_strided(la, wm * 8 + i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = BKC ? frag_read<true>(lb, wn * 4 + j, ks, lane) : huge_frag_strided(lb, wn * 4 + j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (!AKC && do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, acc1[i], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (!AKC && do_rowsum && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 128 + i * 16 + (lane >> 4) * 4 + r;
+                if (row < g.M) atomicAdd(g.e.rowsum_a + row, acc1[i][r] * g.e.alpha);
+            }
+    }
+
+    float* cl = (float*)smem;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        if ((wn >> 1) == h) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = wm * 128 + i * 16 + (lane >> 4) * 4 + r;
+                        int col = (wn & 1) * 64 + j * 16 + (lane & 15);
+                        cl[row * CSTRIDE + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        gemm_epilogue<BIG_BM, 512>(g, cl, m0, n0 + h * 128);
+        __syncthreads();
+    }
+}
+
+// test hook: route everything through the 128x128 kernel (set by LAV_GEMM_SMALL=1)
+static const bool lav_gemm_force_small = getenv("LAV_GEMM_SMALL") != nullptr;
+static const bool lav_gemm_no_huge = getenv("LAV_GEMM_NO_HUGE") != nullptr;
+static const bool lav_gemm_tn_huge = getenv("LAV_GEMM_TN_HUGE") != nullptr;   // experiment: 256x256 weight-gradient tiles (slower)
 
 extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B,
                              long ldb, void* C, long ldc, const lav_gemm_epilogue* epi, int splits) {
@@ -344,6 +675,49 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         hipFuncSetAttribute((const void*)gemm_kernel<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         (void)hipGetLastError();
         attr_set = true;
+    }
+    const bool big = layout != 2 && splits == 1 && (K % BKT) == 0 && M >= 2048 && !lav_gemm_force_small;
+    static bool huge_attr = false;
+    if (!huge_attr) {
+        hipFuncSetAttribute((const void*)gemm_huge_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HUGE_LDS);
+        hipFuncSetAttribute((const void*)gemm_huge_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, HUGE_LDS);
+        hipFuncSetAttribute((const void*)gemm_huge_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, HUGE_LDS);
+        (void)hipGetLastError();
+        huge_attr = true;
+    }
+    // pick the tile by estimated machine fill: tiles / (rounds * resident slots), weighted by the tile's own efficiency
+    auto fill = [](long tiles, long slots, double w) { return w * (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
+    const long t_small = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const long t_big = (long)((M + BIG_BM - 1) / BIG_BM) * ((N + BN - 1) / BN);
+    const long t_huge = (long)((M + BIG_BM - 1) / BIG_BM) * (N / 256);
+    const double f_small = fill(t_small, 512, 0.80), f_big = fill(t_big, 256, 0.88);
+    const double f_huge = (N % 256) == 0 ? fill(t_huge, 256, 1.0) : 0.0;
+    if (big && !lav_gemm_no_huge && f_huge >= f_big && f_huge >= f_small) {
+        g.k_per_split = K;
+        dim3 hgrid((unsigned)t_huge);
+        if (layout == 0) hipLaunchKernelGGL((gemm_huge_kernel<true, true>), hgrid, dim3(512), HUGE_LDS, s, g);
+        else hipLaunchKernelGGL((gemm_huge_kernel<true, false>), hgrid, dim3(512), HUGE_LDS, s, g);
+        return lav_check_launch("lav_gemm_bf16");
+    }
+    // weight gradients with 256-multiple outputs: square tiles quarter the fp32-atomic traffic per flop
+    if (lav_gemm_tn_huge && layout == 2 && (N % 256) == 0 && M >= 256 && (K % BKT) == 0 && (kps % BKT) == 0 && !g.e.k_keep &&
+        g.e.out_mode == 2) {
+        dim3 hgrid(((M + BIG_BM - 1) / BIG_BM) * (N / 256), 1, splits);
+        hipLaunchKernelGGL((gemm_huge_kernel<false, false>), hgrid, dim3(512), HUGE_LDS, s, g);
+        return lav_check_launch("lav_gemm_bf16");
+    }
+    if (big && f_big >= f_small) {
+        static bool big_attr = false;
+        if (!big_attr) {
+            hipFuncSetAttribute((const void*)gemm_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+            hipFuncSetAttribute((const void*)gemm_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+            (void)hipGetLastError();
+            big_attr = true;
+        }
+        dim3 bgrid(((M + BIG_BM - 1) / BIG_BM) * ((N + BN - 1) / BN));
+        if (layout == 0) hipLaunchKernelGGL((gemm_big_kernel<true>), bgrid, dim3(512), BIG_LDS, s, g);
+        else hipLaunchKernelGGL((gemm_big_kernel<false>), bgrid, dim3(512), BIG_LDS, s, g);
+        return lav_check_launch("lav_gemm_bf16");
     }
     if (layout == 0) hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, block, GEMM_LDS_BYTES, s, g);
     else if (layout == 1) hipLaunchKernelGGL((gemm_kernel<true, false, 1>), grid, block, GEMM_LDS_BYTES, s, g);

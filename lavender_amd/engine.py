@@ -114,7 +114,7 @@ class SwinBlockFn(torch.autograd.Function):
         dy = dy.contiguous()
         # --- MLP branch: out = x_mid + s * fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------
         K.gemm(2, dy, h, C, 4 * C, M, out=G(mlp.fc2.weight), accumulate=True, k_keep=dp_mlp, k_rows_per_group=rpg,
-               alpha=alpha if dp_mlp is not None else 1.0, splits=K.splits_for(C, 4 * C, M), rowsum_a=G(mlp.fc2.bias))
+               alpha=alpha if dp_mlp is not None else 1.0, splits=K.splits_for(C, 4 * C, M, dp_mlp is not None), rowsum_a=G(mlp.fc2.bias))
         dh = K.gemm(1, dy, W16(mlp.fc2.weight), M, 4 * C, C, gelu_in=h_pre, row_scale=dp_mlp, rows_per_group=rpg,
                     colsum=G(mlp.fc1.bias))
         K.gemm(2, dh, y2, 4 * C, C, M, out=G(mlp.fc1.weight), accumulate=True, splits=K.splits_for(4 * C, C, M))
@@ -124,7 +124,7 @@ class SwinBlockFn(torch.autograd.Function):
                                 add_in=dy)
         # --- attention branch: x_mid = x + s * proj(attn(qkv(LN1(x)))) ---------------------------------
         K.gemm(2, d_mid, ao, C, C, M, out=G(a.proj.weight), accumulate=True, k_keep=dp_attn, k_rows_per_group=rpg,
-               alpha=alpha if dp_attn is not None else 1.0, splits=K.splits_for(C, C, M), rowsum_a=G(a.proj.bias))
+               alpha=alpha if dp_attn is not None else 1.0, splits=K.splits_for(C, C, M, dp_attn is not None), rowsum_a=G(a.proj.bias))
         d_ao = K.gemm(1, d_mid, W16(a.proj.weight), M, C, C, row_scale=dp_attn, rows_per_group=rpg)
         dqkv = torch.empty_like(qkv)
         att.bwd(qkv, ao, d_ao, lse, dqkv, G(a.relative_position_bias_table))

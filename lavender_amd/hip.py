@@ -67,9 +67,9 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
     return out[:, :N] if out.shape[-1] != N else out
 
 
-def splits_for(M, N, K):
-    """split-K factor for weight-gradient GEMMs.  Measured on MI355X (tools/tn_probe.py): the 8-wave TN kernel is
-    fastest at about 190-260 blocks (<= one per CU); every extra split adds a full fp32-atomic output tile."""
+def splits_for(M, N, K, keep=False):
+    """split-K factor for weight-gradient GEMMs.  Measured on MI355X (tools/tn_probe.py): the 8-wave 128x128 TN kernel
+    is fastest at about 190-260 blocks (<= one per CU); every extra split adds a full fp32-atomic output tile."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 200:
         return 1

@@ -45,6 +45,23 @@ def test_gemm_layouts(layout, shape):
     close(out, a @ b, atol=1e-3 * math.sqrt(Kd), rtol=1e-3, what=f"gemm layout {layout} {shape}")
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("shape", [(2304, 256, 128), (4100, 512, 192), (2500, 384, 64), (3000, 1000, 256)])
+def test_gemm_large_m_kernels(layout, shape):
+    """M >= 2048 routes to the 256x128 (three-stage) or, when N % 256 == 0, the 256x256 direct-to-LDS kernels;
+    the fused epilogue must behave identically there (bias + GELU + residual + column sums)."""
+    M, N, Kd = shape
+    A = rb(M, Kd)
+    B = rb(N, Kd, seed=1, scale=0.2) if layout == 0 else rb(Kd, N, seed=1, scale=0.2)
+    bias, res = torch.randn(N).cuda(), rb(M, N, seed=2)
+    cs = torch.zeros(N, device="cuda")
+    out = K().gemm(layout, A, B, M, N, Kd, bias=bias, act=1, residual=res, colsum=cs)
+    b = B.float().t() if layout == 0 else B.float()
+    ref = F.gelu(A.float() @ b + bias) + res.float()
+    close(out, ref, atol=3e-2, what=f"large-M gemm layout {layout} {shape}")
+    close(cs, ref.sum(0), atol=2.0, rtol=2e-2, what="colsum")
+
+
 def test_gemm_epilogue_bias_gelu_preact_residual_rowscale():
     M, N, Kd = 300, 264, 128
     A, W, res = rb(M, Kd), rb(N, Kd, seed=1, scale=0.1), rb(M, N, seed=2)

@@ -21,8 +21,8 @@ for (M, N, Kd) in shapes:
     out = torch.zeros(M, N, device="cuda")
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     res = []
-    for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256):
-        if tiles * s > 4096 or Kd // s < 64: continue
+    for s in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256):
+        if tiles * s > 4096 or Kd // s < 512: continue
         t = bench(lambda: K.gemm(2, A, B, M, N, Kd, out=out, accumulate=True, splits=s))
         res.append((t, s))
     best = min(res)
