@@ -93,10 +93,15 @@ extern "C" int lav_scale_by_count(void* stream, long n_elems, void* x_bf16, cons
 }
 
 // ---- optimizer over the flat arena ------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* g, float* out) {
+// sum of squares, DETERMINISTIC (fixed grid, fixed reduction order): the clip coefficient derived from it must be
+// bit-identical on every data-parallel rank, otherwise the replicas drift apart by ulps per step.
+#define SUMSQ_BLOCKS 1024
+__device__ float g_sumsq_partial[SUMSQ_BLOCKS];
+
+__global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* g) {
     float s = 0.f;
     const long n4 = n / 4;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)SUMSQ_BLOCKS * 256) {
         float4 v = ((const float4*)g)[i];
         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
@@ -106,14 +111,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* g, floa
     __shared__ float sh[4];
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) g_sumsq_partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(float* out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < SUMSQ_BLOCKS; i += 256) s += g_sumsq_partial[i];
+    s = wave_sum(s);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] += (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 extern "C" int lav_sumsq_f32(void* stream, long n, const float* g, float* out) {
     LAV_REQUIRE(n > 0 && g && out && ((uintptr_t)g % 16) == 0, "lav_sumsq_f32: bad arguments");
-    int grid = (int)((n / 4 + 255) / 256 > 2048 ? 2048 : (n / 4 + 255) / 256);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, g, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, n, g);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out);
     return lav_check_launch("lav_sumsq_f32");
 }
 

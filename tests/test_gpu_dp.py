@@ -1,0 +1,74 @@
+"""GPU: two data-parallel ranks (processes) sharing the one visible MI355X, process group over gloo (RCCL needs one
+device per rank; the code path through lavender_amd.dp.ArenaReducer is the same): after backward + finish() every
+rank holds the SUM of the per-rank gradients, parameters were broadcast from rank 0, and one optimizer step with
+grad_div = world keeps the replicas bit-identical."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rank_grads(rank, agent, m):
+    from tests.helpers import BERT_CFGS, make_batch
+    b = make_batch(2, vocab=BERT_CFGS["micro"]["vocab"], seed=10 + rank)
+    torch.manual_seed(5 + rank)
+    b.update(agent.masking(b["txt"], b["mask"]))
+    batch = agent.prepare_batch(b)
+    m.eval()                                            # deterministic (no dropout) so ranks can be replayed
+    m.arena().zero_grad()
+    np.random.seed(rank)
+    out = m(batch)
+    ls = agent.loss_func(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten()) + \
+        agent.loss_func(out["out_vtm"].flatten(0, 1), out["ans_vtm"].flatten())
+    ls.backward()
+    return m.arena().grad.clone()
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lavender_amd as LA
+    from tests.helpers import Tok, make_args
+    torch.manual_seed(100 + rank)                       # different initial weights: the broadcast must fix that
+    m = LA.LAVENDER_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3), Tok()).cuda()
+    m.arena()
+    agent = LA.Agent_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3), m)
+    agent.prepare_dist_model()
+    assert agent.dp is not None and agent.dp.world == world
+    w0 = m.arena().master.clone()
+    g_own = _rank_grads(rank, agent, m)
+    agent.dp.finish()
+    g_sum = m.arena().grad.clone()
+    # replay the other rank's batch locally (same weights after the broadcast) and compare
+    g_other = _rank_grads(1 - rank, agent, m)
+    rel = ((g_own + g_other) - g_sum).norm() / g_sum.norm()
+    m.arena().grad.copy_(g_sum)
+    agent.optzr.step(max_norm=1.0, grad_div=float(world))
+    torch.cuda.synchronize()
+    q.put((rank, float(rel), float(w0.double().sum()), float(m.arena().master.double().sum())))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_allreduce_and_replica_consistency():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1000)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    (r0, rel0, w0a, w0b), (r1, rel1, w1a, w1b) = res
+    assert rel0 < 2e-2 and rel1 < 2e-2, (rel0, rel1)            # sum of per-rank grads (atomics: order-dependent fp32 rounding)
+    assert w0a == w1a                                            # broadcast from rank 0
+    assert w0b == w1b and w0b != w0a                             # identical update on both replicas
