@@ -43,9 +43,10 @@ int lav_abi_version(void);
 typedef struct lav_gemm_epilogue {
     const float* bias;        /* [N] fp32 or NULL */
     int act;                  /* 0 none, 1 exact (erf) GELU */
-    void* preact;             /* bf16 [M, ldp]: receives alpha*acc+bias before the activation, or NULL */
+    void* preact;             /* bf16 [M, ldp]: receives z = alpha*acc+bias before the activation (or GELU'(z) when
+                                 preact_is_grad), or NULL */
     long ldp;
-    const void* gelu_in;      /* bf16 [M, ldg]: multiply by gelu'(gelu_in), or NULL */
+    const void* gelu_in;      /* bf16 [M, ldg]: multiply by gelu'(gelu_in) (or by gelu_in itself when gelu_in_is_grad) */
     long ldg;
     float dropout_p;          /* hidden dropout (BertSelfOutput/BertOutput), mask = f(seed, row*N+col) */
     uint32_t seed;
@@ -60,6 +61,8 @@ typedef struct lav_gemm_epilogue {
     int k_rows_per_group;
     float* rowsum_a;          /* layout 2 only: fp32 [M] += alpha * sum_k A[k, m] -- the bias gradient sum(dy), fused
                                  into the weight-gradient GEMM on the matrix cores (no extra pass over dy) */
+    int preact_is_grad;       /* forward: store GELU'(z) instead of z (the backward then needs one multiply, no erf) */
+    int gelu_in_is_grad;      /* backward: gelu_in already holds GELU'(z) */
 } lav_gemm_epilogue;
 
 int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B, long ldb,

@@ -28,7 +28,7 @@ class GemmEpilogue(C.Structure):
     _fields_ = [("bias", vp), ("act", i32), ("preact", vp), ("ldp", i64), ("gelu_in", vp), ("ldg", i64),
                 ("dropout_p", f32), ("seed", u32), ("row_scale", vp), ("rows_per_group", i32), ("residual", vp),
                 ("ldr", i64), ("colsum", vp), ("alpha", f32), ("out_mode", i32), ("k_keep", vp),
-                ("k_rows_per_group", i32), ("rowsum_a", vp)]
+                ("k_rows_per_group", i32), ("rowsum_a", vp), ("preact_is_grad", i32), ("gelu_in_is_grad", i32)]
 
 
 class LnGather(C.Structure):

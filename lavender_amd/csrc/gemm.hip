@@ -150,8 +150,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             if (x < ncols) bias[x] = e.bias[gcol + x];
     }
     const bool full = ncols == 8;
+    constexpr int NIT = ROWS / (NTHR / 16);
+    constexpr int GRP = 4;                                 // rows handled together: their gelu_in / residual loads are
+    static_assert(NIT % GRP == 0, "epilogue row grouping");  // issued back-to-back so HBM latency is paid once per group
 #pragma unroll 1
-    for (int j = 0; j < ROWS / (NTHR / 16); ++j) {
+    for (int j0 = 0; j0 < NIT; j0 += GRP) {
+        uint4 pre_g[GRP], pre_r[GRP];
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            const int grow = m0 + (etid >> 4) + (NTHR / 16) * (j0 + u);
+            pre_g[u] = make_uint4(0, 0, 0, 0); pre_r[u] = pre_g[u];
+            if (full && grow < g.M) {
+                if (e.gelu_in) pre_g[u] = *(const uint4*)((const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol);
+                if (e.residual) pre_r[u] = *(const uint4*)((const bf16_t*)e.residual + (long)grow * e.ldr + gcol);
+            }
+        }
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const int j = j0 + u;
         const int row = (etid >> 4) + (NTHR / 16) * j;
         const int grow = m0 + row;
         if (grow >= g.M || ncols <= 0) continue;
@@ -160,22 +176,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         *(float4*)&v[4] = *(const float4*)&cl[row * CSTRIDE + cc * 8 + 4];
 #pragma unroll
         for (int x = 0; x < 8; ++x) v[x] = v[x] * e.alpha + bias[x];
-        if (e.preact) {
+        if (e.preact && !e.preact_is_grad) {
             bf16_t* p = (bf16_t*)e.preact + (long)grow * e.ldp + gcol;
             if (full) *(uint4*)p = pack8(v);
             else for (int x = 0; x < ncols; ++x) p[x] = f2bf(v[x]);
         }
         if (e.act == 1) {
+            if (e.preact && e.preact_is_grad) {
+                // GELU and GELU' share erf and exp: y = z Phi(z), y' = Phi(z) + z phi(z); y' is what the backward needs
+                float gp[8];
 #pragma unroll
-            for (int x = 0; x < 8; ++x) v[x] = gelu_f(v[x]);
+                for (int x = 0; x < 8; ++x) {
+                    const float z = v[x];
+                    const float cdf = 0.5f * (1.0f + fast_erf(z * 0.70710678118654752f));
+                    gp[x] = cdf + z * 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * z * z);
+                    v[x] = z * cdf;
+                }
+                bf16_t* p = (bf16_t*)e.preact + (long)grow * e.ldp + gcol;
+                if (full) *(uint4*)p = pack8(gp);
+                else for (int x = 0; x < ncols; ++x) p[x] = f2bf(gp[x]);
+            } else {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) v[x] = gelu_f(v[x]);
+            }
         }
         if (e.gelu_in) {
             const bf16_t* p = (const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol;
             float h[8];
-            if (full) { uint4 u = *(const uint4*)p; unpack8(u, h); }
+            if (full) unpack8(pre_g[u], h);
             else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? bf2f(p[x]) : 0.f;
+            if (e.gelu_in_is_grad) {
 #pragma unroll
-            for (int x = 0; x < 8; ++x) v[x] *= gelu_grad_f(h[x]);
+                for (int x = 0; x < 8; ++x) v[x] *= h[x];
+            } else {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) v[x] *= gelu_grad_f(h[x]);
+            }
         }
         if (e.dropout_p > 0.f) {
             const float inv = 1.0f / (1.0f - e.dropout_p);
@@ -191,7 +227,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         if (e.residual) {
             const bf16_t* p = (const bf16_t*)e.residual + (long)grow * e.ldr + gcol;
             float h[8];
-            if (full) { uint4 u = *(const uint4*)p; unpack8(u, h); }
+            if (full) unpack8(pre_r[u], h);
             else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? bf2f(p[x]) : 0.f;
 #pragma unroll
             for (int x = 0; x < 8; ++x) v[x] += h[x];
@@ -212,6 +248,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             float* p = (float*)g.C + (long)grow * g.ldc + gcol;
             for (int x = 0; x < ncols; ++x) atomicAdd(p + x, v[x]);
         }
+      }
     }
     if (e.colsum) {
         __syncthreads();
@@ -419,7 +456,31 @@ __device__ __forceinline__ void big_glds(char* lds, const bf16_t* __restrict__ P
     }
 }
 
-template <bool BKC>
+__device__ __forceinline__ void huge_glds_strided(char* lds, const bf16_t* __restrict__ P, long ld, int o0, int O, int k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                          // [64 k][256 n] bf16, 512-byte rows, 2 rows per wave-instruction
+        const int t = wave * 4 + i;
+        const int krow = t * 2 + (lane >> 5);
+        const int ch = ((lane & 31) >> 1) ^ skey(krow);
+        const int col = min(o0 + ch * 16 + (lane & 1) * 8, ((O + 7) & ~7) - 8);
+        const bf16_t* src = P + (long)(k0 + krow) * ld + col;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + t * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8 huge_frag_strided(const char* lds, int t16, int ks, int lane) {
+    const int i = lane & 15, g = lane >> 4, r = i >> 2, c = i & 3;
+    const int k = ks * 32 + 8 * g + r;
+    const int ch = (t16 ^ skey(k)) << 5;
+    s16x4 lo = tr_read(lds, k * 512 + ch + c * 8);
+    s16x4 hi = tr_read(lds, (k + 4) * 512 + ch + c * 8);
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+template <bool AKC, bool BKC>
 __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -432,20 +493,33 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int m0 = (bid / tiles_n) * BIG_BM, n0 = (bid % tiles_n) * BN;
-    const int nk = g.K / BKT;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nk = (kend - kbeg) / BKT;
 
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // TN: bias gradient on the matrix cores (ones fragment), wn == 0 waves of the n0 == 0 blocks
+    const bool do_rowsum = !AKC && g.e.rowsum_a != nullptr && n0 == 0 && wn == 0;
+    f32x4 acc1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+    {
+        union { uint4 u; bf16x8 b; } o; o.u = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); ones = o.b;
+    }
 
     auto issue = [&](int kt) {
         char* st = smem + (kt % 3) * BIG_STAGE;
-        big_glds<true, 4>(st, g.A, g.lda, m0, g.M, kt * BKT, wave, lane);            // 256 rows x 128 B = 32 instr
-        big_glds<BKC, 2>(st + 32768, g.B, g.ldb, n0, g.N, kt * BKT, wave, lane);     // 16 KB = 16 instr
+        const int k0 = kbeg + kt * BKT;
+        if (AKC) big_glds<true, 4>(st, g.A, g.lda, m0, g.M, k0, wave, lane);          // 256 rows x 128 B = 32 instr
+        else huge_glds_strided(st, g.A, g.lda, m0, g.M, k0, wave, lane);              // [64 k][256 m], 32 instr
+        big_glds<BKC, 2>(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);            // 16 KB = 16 instr
     };
-    issue(0);
+    if (nk > 0) issue(0);
     if (nk > 1) {
         issue(1);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -459,34 +533,36 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
         const char* lb = la + 32768;
         const bool more = kt + 2 < nk;
         if (more) issue(kt + 2);
-        {
-            // all 16 fragment reads of the k-tile are issued up front; the MFMAs of k-step 0 start as soon as ITS
-            // eight fragments have landed (counted lgkmcnt) and cover the flight of k-step 1's fragments
-            bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa0[i] = frag_read<true>(la, wm * 4 + i, 0, lane);
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb0[j] = frag_read<BKC>(lb, wn * 4 + j, 0, lane);
+            for (int i = 0; i < 4; ++i) fa[i] = AKC ? frag_read<true>(la, wm * 4 + i, ks, lane) : huge_frag_strided(la, wm * 4 + i, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa1[i] = frag_read<true>(la, wm * 4 + i, 1, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb1[j] = frag_read<BKC>(lb, wn * 4 + j, 1, lane);
-            __builtin_amdgcn_sched_barrier(0);            // keep the 16 reads above the MFMAs (hipcc otherwise sinks them)
+            for (int j = 0; j < 4; ++j) fb[j] = frag_read<BKC>(lb, wn * 4 + j, ks, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (!AKC && do_rowsum) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, acc1[i], 0, 0, 0);
+            }
         }
         // tile kt+1 must have landed (6 wave-instructions per tile per wave; keep tile kt+2 in flight)
         if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+    }
+    if (!AKC && do_rowsum && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (row < g.M) atomicAdd(g.e.rowsum_a + row, acc1[i][r] * g.e.alpha);
+            }
     }
 
     float* cl = (float*)smem;
@@ -513,30 +589,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------------
 #define HUGE_STAGE 65536
 #define HUGE_LDS (BIG_BM * CSTRIDE * 4 > 2 * HUGE_STAGE ? BIG_BM * CSTRIDE * 4 : 2 * HUGE_STAGE)
-
-__device__ __forceinline__ void huge_glds_strided(char* lds, const bf16_t* __restrict__ P, long ld, int o0, int O, int k0, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                          // [64 k][256 n] bf16, 512-byte rows, 2 rows per wave-instruction
-        const int t = wave * 4 + i;
-        const int krow = t * 2 + (lane >> 5);
-        const int ch = ((lane & 31) >> 1) ^ skey(krow);
-        const int col = min(o0 + ch * 16 + (lane & 1) * 8, ((O + 7) & ~7) - 8);
-        const bf16_t* src = P + (long)(k0 + krow) * ld + col;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + t * 1024), 16, 0, 0);
-    }
-}
-
-__device__ __forceinline__ bf16x8 huge_frag_strided(const char* lds, int t16, int ks, int lane) {
-    const int i = lane & 15, g = lane >> 4, r = i >> 2, c = i & 3;
-    const int k = ks * 32 + 8 * g + r;
-    const int ch = (t16 ^ skey(k)) << 5;
-    s16x4 lo = tr_read(lds, k * 512 + ch + c * 8);
-    s16x4 hi = tr_read(lds, (k + 4) * 512 + ch + c * 8);
-    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-    u.s.a = lo; u.s.b = hi;
-    return u.v;
-}
 
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
@@ -640,7 +692,7 @@ __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
 // test hook: route everything through the 128x128 kernel (set by LAV_GEMM_SMALL=1)
 static const bool lav_gemm_force_small = getenv("LAV_GEMM_SMALL") != nullptr;
 static const bool lav_gemm_no_huge = getenv("LAV_GEMM_NO_HUGE") != nullptr;
-static const bool lav_gemm_tn_huge = getenv("LAV_GEMM_TN_HUGE") != nullptr;   // experiment: 256x256 weight-gradient tiles (slower)
+static const bool lav_gemm_tn_big = getenv("LAV_GEMM_TN_BIG") != nullptr;
 
 extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B,
                              long ldb, void* C, long ldc, const lav_gemm_epilogue* epi, int splits) {
@@ -699,24 +751,33 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         else hipLaunchKernelGGL((gemm_huge_kernel<true, false>), hgrid, dim3(512), HUGE_LDS, s, g);
         return lav_check_launch("lav_gemm_bf16");
     }
-    // weight gradients with 256-multiple outputs: square tiles quarter the fp32-atomic traffic per flop
-    if (lav_gemm_tn_huge && layout == 2 && (N % 256) == 0 && M >= 256 && (K % BKT) == 0 && (kps % BKT) == 0 && !g.e.k_keep &&
-        g.e.out_mode == 2) {
-        dim3 hgrid(((M + BIG_BM - 1) / BIG_BM) * (N / 256), 1, splits);
-        hipLaunchKernelGGL((gemm_huge_kernel<false, false>), hgrid, dim3(512), HUGE_LDS, s, g);
+    // weight gradients on the 256x128 three-stage kernel: opt-in experiment (LAV_GEMM_TN_BIG=1).  Measured on MI355X it
+    // ties the 8-wave 128x128 split-K kernel per call and loses in the full step (167 vs 161 ms): with so few output
+    // tiles the machine fill (tiles x splits vs 256 CUs) decides, and the smaller tile quantises better.
+    if (layout == 2 && M >= 256 && (K % BKT) == 0 && (kps % BKT) == 0 && !g.e.k_keep && g.e.out_mode == 2 &&
+        !lav_gemm_force_small && lav_gemm_tn_big) {
+        static bool tn_attr = false;
+        if (!tn_attr) {
+            hipFuncSetAttribute((const void*)gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+            (void)hipGetLastError();
+            tn_attr = true;
+        }
+        dim3 tgrid(((M + BIG_BM - 1) / BIG_BM) * ((N + BN - 1) / BN), 1, splits);
+        hipLaunchKernelGGL((gemm_big_kernel<false, false>), tgrid, dim3(512), BIG_LDS, s, g);
         return lav_check_launch("lav_gemm_bf16");
     }
     if (big && f_big >= f_small) {
         static bool big_attr = false;
         if (!big_attr) {
-            hipFuncSetAttribute((const void*)gemm_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
-            hipFuncSetAttribute((const void*)gemm_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+            hipFuncSetAttribute((const void*)gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+            hipFuncSetAttribute((const void*)gemm_big_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
             (void)hipGetLastError();
             big_attr = true;
         }
         dim3 bgrid(((M + BIG_BM - 1) / BIG_BM) * ((N + BN - 1) / BN));
-        if (layout == 0) hipLaunchKernelGGL((gemm_big_kernel<true>), bgrid, dim3(512), BIG_LDS, s, g);
-        else hipLaunchKernelGGL((gemm_big_kernel<false>), bgrid, dim3(512), BIG_LDS, s, g);
+        g.k_per_split = K;
+        if (layout == 0) hipLaunchKernelGGL((gemm_big_kernel<true, true>), bgrid, dim3(512), BIG_LDS, s, g);
+        else hipLaunchKernelGGL((gemm_big_kernel<true, false>), bgrid, dim3(512), BIG_LDS, s, g);
         return lav_check_launch("lav_gemm_bf16");
     }
     if (layout == 0) hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, block, GEMM_LDS_BYTES, s, g);

@@ -90,7 +90,7 @@ class SwinBlockFn(torch.autograd.Function):
                        residual=x)
         y2, mean2, rstd2 = K.layernorm_fwd(x_mid, M, C, blk.norm2.weight.data, blk.norm2.bias.data, 1e-5, want_stats=keep)
         h_pre = torch.empty((M, 4 * C), dtype=bf16, device=x.device) if keep else None
-        h = K.gemm(0, y2, W16(mlp.fc1.weight), M, 4 * C, C, bias=mlp.fc1.bias.data, act=1, preact=h_pre)
+        h = K.gemm(0, y2, W16(mlp.fc1.weight), M, 4 * C, C, bias=mlp.fc1.bias.data, act=1, preact=h_pre, preact_is_grad=True)
         out = K.gemm(0, h, W16(mlp.fc2.weight), M, C, 4 * C, bias=mlp.fc2.bias.data, row_scale=dp_mlp, rows_per_group=rpg,
                      residual=x_mid)
         if keep:
@@ -115,8 +115,8 @@ class SwinBlockFn(torch.autograd.Function):
         # --- MLP branch: out = x_mid + s * fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------
         K.gemm(2, dy, h, C, 4 * C, M, out=G(mlp.fc2.weight), accumulate=True, k_keep=dp_mlp, k_rows_per_group=rpg,
                alpha=alpha if dp_mlp is not None else 1.0, splits=K.splits_for(C, 4 * C, M, dp_mlp is not None), rowsum_a=G(mlp.fc2.bias))
-        dh = K.gemm(1, dy, W16(mlp.fc2.weight), M, 4 * C, C, gelu_in=h_pre, row_scale=dp_mlp, rows_per_group=rpg,
-                    colsum=G(mlp.fc1.bias))
+        dh = K.gemm(1, dy, W16(mlp.fc2.weight), M, 4 * C, C, gelu_in=h_pre, gelu_in_is_grad=True, row_scale=dp_mlp,
+                    rows_per_group=rpg, colsum=G(mlp.fc1.bias))
         K.gemm(2, dh, y2, 4 * C, C, M, out=G(mlp.fc1.weight), accumulate=True, splits=K.splits_for(4 * C, C, M))
         d_y2 = K.gemm(1, dh, W16(mlp.fc1.weight), M, C, 4 * C)
         del dh
@@ -319,7 +319,7 @@ class BertLayerFn(torch.autograd.Function):
         inter, outp = layer.intermediate, layer.output
         F = inter.dense.weight.shape[0]
         h_pre = torch.empty((R, F), dtype=bf16, device=x.device) if keep else None
-        h = K.gemm(0, x1, W16(inter.dense.weight), R, F, Hd, bias=inter.dense.bias.data, act=1, preact=h_pre)
+        h = K.gemm(0, x1, W16(inter.dense.weight), R, F, Hd, bias=inter.dense.bias.data, act=1, preact=h_pre, preact_is_grad=True)
         pre2 = K.gemm(0, h, W16(outp.dense.weight), R, Hd, F, bias=outp.dense.bias.data, dropout_p=p_hidden, seed=s2, residual=x1)
         y, mean2, rstd2 = K.layernorm_fwd(pre2, R, Hd, outp.LayerNorm.weight.data, outp.LayerNorm.bias.data, outp.LayerNorm.eps,
                                           want_stats=keep)
@@ -344,7 +344,7 @@ class BertLayerFn(torch.autograd.Function):
         d_pre2 = K.layernorm_bwd(dy, pre2, R, Hd, outp.LayerNorm.weight.data, mean2, rstd2, G(outp.LayerNorm.weight),
                                  G(outp.LayerNorm.bias), dx2=d_dense2, dropout_p=p, seed=s2, colsum=G(outp.dense.bias))
         K.gemm(2, d_dense2, h, Hd, F, R, out=G(outp.dense.weight), accumulate=True, splits=K.splits_for(Hd, F, R))
-        dh = K.gemm(1, d_dense2, W16(outp.dense.weight), R, F, Hd, gelu_in=h_pre, colsum=G(inter.dense.bias))
+        dh = K.gemm(1, d_dense2, W16(outp.dense.weight), R, F, Hd, gelu_in=h_pre, gelu_in_is_grad=True, colsum=G(inter.dense.bias))
         K.gemm(2, dh, x1, F, Hd, R, out=G(inter.dense.weight), accumulate=True, splits=K.splits_for(F, Hd, R))
         d_x1 = K.gemm(1, dh, W16(inter.dense.weight), R, Hd, F, residual=d_pre2)
         del dh

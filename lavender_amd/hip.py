@@ -35,7 +35,7 @@ def _ld(t):
 
 def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, preact=None, gelu_in=None, dropout_p=0.0,
          seed=0, row_scale=None, rows_per_group=1, residual=None, colsum=None, alpha=1.0, accumulate=False,
-         k_keep=None, k_rows_per_group=1, splits=1, ldc=None, rowsum_a=None):
+         k_keep=None, k_rows_per_group=1, splits=1, ldc=None, rowsum_a=None, preact_is_grad=False, gelu_in_is_grad=False):
     """layout 0: A[M,K] B[N,K]; 1: A[M,K] B[K,N]; 2: A[K,M] B[K,N].  Returns the (M, N) output view."""
     dev = A.device
     if out is None:
@@ -62,6 +62,8 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
     e.k_keep = _p(k_keep)
     e.k_rows_per_group = int(k_rows_per_group)
     e.rowsum_a = _p(rowsum_a)
+    e.preact_is_grad = int(preact_is_grad)
+    e.gelu_in_is_grad = int(gelu_in_is_grad)
     L.check(L.lib.lav_gemm_bf16(_s(), layout, M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc, C.byref(e), splits),
             "lav_gemm_bf16")
     return out[:, :N] if out.shape[-1] != N else out
