@@ -87,54 +87,78 @@ __global__ __launch_bounds__(256) void video_embed_fwd_kernel(int B, int T, int 
     if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
 }
 
-template <int MAXC>
+// backward: one block per token position p' (0 = cls): it walks the B*T rows that share the position embedding, so
+// d_pos[p'] is a private register sum (one atomic per element per block instead of one per row), d_len[t] and
+// dgamma / dbeta are accumulated per block before touching global memory.
 __global__ __launch_bounds__(256) void video_embed_bwd_kernel(int B, int T, int hw, int Hd, const bf16_t* __restrict__ dout, long seq_rows,
                                                              const bf16_t* __restrict__ feat, const float* cls, const float* pos,
                                                              const float* len, const float* gamma, const float* mean_i,
                                                              const float* rstd_i, bf16_t* __restrict__ dfeat, float* d_cls, float* d_pos,
                                                              float* d_len, float* dgamma, float* dbeta) {
-    const int lane = threadIdx.x & 63;
-    const int P = 1 + hw;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= (long)B * T * P) return;
-    const int pp = r % P; const int bt = r / P; const int t = bt % T, b = bt / T;
-    const float mean = mean_i[r], rstd = rstd_i[r];
-    const bf16_t* dy = dout + ((long)b * seq_rows + (long)t * P + pp) * Hd;
-    float xh[MAXC][8], gy[MAXC][8];
-    float s1 = 0.f, s2 = 0.f;
+    __shared__ float red[2][4];
+    const int P = 1 + hw, pp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int MAXJ = 4;                               // columns per thread: Hd <= 1024
+    float xpos[MAXJ], gam[MAXJ], a_pos[MAXJ], a_g[MAXJ], a_b[MAXJ];
 #pragma unroll
-    for (int it = 0; it < MAXC; ++it) {
-        const int col = (it * 64 + lane) * 8;
-        if (col < Hd) {
-            float x[8], d[8];
-            if (pp == 0) { for (int k = 0; k < 8; ++k) x[k] = cls[col + k]; }
-            else { uint4 u = *(const uint4*)(feat + ((long)bt * hw + pp - 1) * Hd + col); unpack8(u, x); }
-            uint4 du = *(const uint4*)(dy + col); unpack8(du, d);
+    for (int j = 0; j < MAXJ; ++j) {
+        const int c = tid + 256 * j;
+        const bool ok = c < Hd;
+        xpos[j] = ok ? pos[(long)pp * Hd + c] + (pp == 0 ? cls[c] : 0.f) : 0.f;
+        gam[j] = ok ? gamma[c] : 0.f;
+        a_pos[j] = a_g[j] = a_b[j] = 0.f;
+    }
+    for (int t = 0; t < T; ++t) {
+        float a_len[MAXJ] = {0.f, 0.f, 0.f, 0.f};
+        float lent[MAXJ];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float xv = x[k] + pos[(long)pp * Hd + col + k] + len[(long)t * Hd + col + k];
-                xh[it][k] = (xv - mean) * rstd;
-                gy[it][k] = gamma[col + k] * d[k];
-                s1 += gy[it][k]; s2 += gy[it][k] * xh[it][k];
-                atomicAdd(dgamma + col + k, d[k] * xh[it][k]);
-                atomicAdd(dbeta + col + k, d[k]);
+        for (int j = 0; j < MAXJ; ++j) { const int c = tid + 256 * j; lent[j] = c < Hd ? len[(long)t * Hd + c] : 0.f; }
+        for (int b = 0; b < B; ++b) {
+            const int bt = b * T + t;
+            const long r = (long)bt * P + pp;
+            const float mean = mean_i[r], rstd = rstd_i[r];
+            const bf16_t* dy = dout + ((long)b * seq_rows + (long)t * P + pp) * Hd;
+            float xh[MAXJ], gy[MAXJ], d[MAXJ];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int c = tid + 256 * j;
+                xh[j] = gy[j] = d[j] = 0.f;
+                if (c < Hd) {
+                    const float f = pp == 0 ? 0.f : bf2f(feat[((long)bt * hw + pp - 1) * Hd + c]);
+                    d[j] = bf2f(dy[c]);
+                    xh[j] = (f + xpos[j] + lent[j] - mean) * rstd;
+                    gy[j] = gam[j] * d[j];
+                    s1 += gy[j]; s2 += gy[j] * xh[j];
+                    a_g[j] += d[j] * xh[j]; a_b[j] += d[j];
+                }
+            }
+            s1 = wave_sum(s1); s2 = wave_sum(s2);
+            __syncthreads();
+            if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+            __syncthreads();
+            const float m1 = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / Hd;
+            const float m2 = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / Hd;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int c = tid + 256 * j;
+                if (c < Hd) {
+                    const float dx = rstd * (gy[j] - m1 - xh[j] * m2);
+                    a_pos[j] += dx; a_len[j] += dx;
+                    if (pp > 0) dfeat[((long)bt * hw + pp - 1) * Hd + c] = f2bf(dx);
+                }
             }
         }
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) { const int c = tid + 256 * j; if (c < Hd) atomicAdd(d_len + (long)t * Hd + c, a_len[j]); }
     }
-    const float m1 = wave_sum(s1) / Hd, m2 = wave_sum(s2) / Hd;
 #pragma unroll
-    for (int it = 0; it < MAXC; ++it) {
-        const int col = (it * 64 + lane) * 8;
-        if (col < Hd) {
-            float dx[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                dx[k] = rstd * (gy[it][k] - m1 - xh[it][k] * m2);
-                atomicAdd(d_pos + (long)pp * Hd + col + k, dx[k]);
-                atomicAdd(d_len + (long)t * Hd + col + k, dx[k]);
-                if (pp == 0) atomicAdd(d_cls + col + k, dx[k]);
-            }
-            if (pp > 0) *(uint4*)(dfeat + ((long)bt * hw + pp - 1) * Hd + col) = pack8(dx);
+    for (int j = 0; j < MAXJ; ++j) {
+        const int c = tid + 256 * j;
+        if (c < Hd) {
+            atomicAdd(d_pos + (long)pp * Hd + c, a_pos[j]);
+            if (pp == 0) atomicAdd(d_cls + c, a_pos[j]);
+            atomicAdd(dgamma + c, a_g[j]);
+            atomicAdd(dbeta + c, a_b[j]);
         }
     }
 }
@@ -156,8 +180,7 @@ extern "C" int lav_video_embed_bwd(void* stream, int B, int T, int hw, int Hd, c
                                    float* dgamma, float* dbeta) {
     LAV_REQUIRE(B > 0 && T > 0 && hw > 0 && Hd % 8 == 0 && Hd <= 1024, "lav_video_embed_bwd: bad shape (Hd=%d)", Hd);
     LAV_REQUIRE(dout && feat && dfeat && d_cls && d_pos && d_len && dgamma && dbeta, "lav_video_embed_bwd: null pointer");
-    long rows = (long)B * T * (1 + hw);
-    hipLaunchKernelGGL(video_embed_bwd_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, B, T, hw, Hd,
+    hipLaunchKernelGGL(video_embed_bwd_kernel, dim3(1 + hw), dim3(256), 0, (hipStream_t)stream, B, T, hw, Hd,
                        (const bf16_t*)dout, seq_rows, (const bf16_t*)feat, emb_cls, emb_pos, emb_len, gamma, mean, rstd,
                        (bf16_t*)dfeat, d_cls, d_pos, d_len, dgamma, dbeta);
     return lav_check_launch("lav_video_embed_bwd");
