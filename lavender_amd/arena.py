@@ -81,6 +81,7 @@ class ParamArena:
         self.v = None
         self.gradsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.anchor = torch.zeros(1, dtype=torch.float32, device=self.device, requires_grad=True)
+        self.listeners = []          # callables(event_name): e.g. the data-parallel reducer
         self.stale = True
         self.sync_half()
 
@@ -111,6 +112,10 @@ class ParamArena:
         lo = min(self.offsets[n] for n in names)
         hi = max(self.offsets[n] + (self.numels[n] + ALIGN - 1) // ALIGN * ALIGN for n in names)
         return lo, hi
+
+    def notify(self, event):
+        for f in self.listeners:
+            f(event)
 
     # -- optimizer ---------------------------------------------------------------------------------
     def zero_grad(self):

@@ -4,9 +4,14 @@ reference's agent.py:252-265 and utils/deepspeed.py).
 One process per GPU; parameters and optimizer state are replicated; the ONLY data-path collective per step is a
 sum all-reduce of the fp32 gradient arena (RCCL over xGMI when the process group backend is "nccl"; "gloo" on CPU
 for tests).  Because gradients already live in one contiguous buffer in execution order, buckets are plain slices:
-no flatten / unflatten copies and no per-parameter hooks.  Buckets are issued back-to-front (the order the backward
-produces them) on a side stream so the tail of the exchange overlaps the optimizer's norm pass of earlier buckets.
-The division by world size is folded into the fused AdamW kernel (grad_div).
+no flatten / unflatten copies and no per-parameter hooks.
+
+Overlap with the backward: the arena is laid out [text embeddings | fusion encoder | video encoder | MLM head | ...].
+The backward finishes the MLM head and all fusion layers (both the MTM and the VTM pass) BEFORE it enters the video
+encoder, so when the first video-side stage starts its backward (engine.VideoEmbedFn) the reducer is notified and
+all-reduces those finished ranges (about half of the 886 MB) on a side stream while the Swin backward -- ~40 % of
+the backward time -- is still running.  finish() reduces what is left.  The division by world size is folded into
+the fused AdamW kernel (grad_div).
 """
 import torch
 import torch.distributed as dist
@@ -23,23 +28,62 @@ class ArenaReducer:
         dist.broadcast(a.master, src=0, group=group)
         a.sync_half()
         self._stream = torch.cuda.Stream() if a.master.is_cuda else None
+        self._done = []          # [lo, hi) ranges already reduced in this step
+        self._works = []
+        self.early_ranges = self._fusion_ranges(a)
+        if hasattr(a, "listeners"):
+            a.listeners.append(self._on_event)
 
-    def buckets(self):
-        n = self.model.arena().total
-        edges = list(range(0, n, self.bucket_elems)) + [n]
+    @staticmethod
+    def _fusion_ranges(a):
+        """Arena ranges whose gradients are final once the backward leaves the fusion side: trsfr.* and fc_mtm.*"""
+        if not hasattr(a, "span") or not hasattr(a, "names"):
+            return []
+        out = []
+        for pre in ("trsfr.", "fc_mtm."):
+            names = [n for n in a.names if n.startswith(pre)]
+            if names:
+                out.append(a.span(names))
+        return out
+
+    def buckets(self, lo=0, hi=None):
+        n = self.model.arena().total if hi is None else hi
+        edges = list(range(lo, n, self.bucket_elems)) + [n]
         return [(edges[i], edges[i + 1]) for i in range(len(edges) - 1)][::-1]
 
-    def finish(self):
-        """All-reduce (sum) every bucket of the gradient arena; returns when the reduced gradients are usable on
-        the current stream."""
+    def _reduce(self, ranges):
         g = self.model.arena().grad
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
-                works = [dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for lo, hi in self.buckets()]
-                for w in works:
+                for lo, hi in ranges:
+                    for b0, b1 in self.buckets(lo, hi):
+                        self._works.append(dist.all_reduce(g[b0:b1], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            for lo, hi in ranges:
+                for b0, b1 in self.buckets(lo, hi):
+                    dist.all_reduce(g[b0:b1], op=dist.ReduceOp.SUM, group=self.group)
+        self._done.extend(ranges)
+
+    def _on_event(self, name):
+        if name == "fusion_grads_final" and not self._done and self.early_ranges:
+            self._reduce(self.early_ranges)
+
+    def finish(self):
+        """Reduce every range not yet reduced in this step; returns when all reduced gradients are usable on the
+        current stream."""
+        total = self.model.arena().total
+        rest, pos = [], 0
+        for lo, hi in sorted(self._done):
+            if lo > pos:
+                rest.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < total:
+            rest.append((pos, total))
+        self._reduce(rest)
+        if self._stream is not None:
+            with torch.cuda.stream(self._stream):
+                for w in self._works:
                     w.wait()
             torch.cuda.current_stream().wait_stream(self._stream)
-        else:
-            for lo, hi in self.buckets():
-                dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        self._works, self._done = [], []

@@ -214,6 +214,11 @@ class VideoEmbedFn(torch.autograd.Function):
         tok, feat, mean, rstd = ctx.saved_tensors
         M, Cl = tok.shape
         Hd = enc.img_feature_dim
+        # every fusion-layer / MLM-head gradient (MTM and VTM pass) is final here: let the data-parallel reducer start
+        # their all-reduce under the video-encoder backward
+        arena = enc._arena_of() if enc._arena_of is not None else None
+        if arena is not None:
+            arena.notify("fusion_grads_final")
         dout = dout.contiguous()
         dfeat = torch.empty((M, Hd), dtype=bf16, device=tok.device)
         K.video_embed_bwd(dout, T * (1 + hw), feat, B, T, hw, Hd, enc.emb_cls.data, enc.emb_pos.data, enc.emb_len.data,

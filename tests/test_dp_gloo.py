@@ -19,7 +19,11 @@ def _worker(rank, world, port, q):
     from lavender_amd.dp import ArenaReducer
     n = 1000 * 64 + 64
     synced = []
-    arena = types.SimpleNamespace(total=n, master=torch.full((n,), float(rank + 1)), grad=torch.zeros(n),
+    names = ["enc_txt.a", "trsfr.layer.0.w", "trsfr.layer.1.w", "enc_img.swin.w", "fc_mtm.w", "emb_task"]
+    offs = {"enc_txt.a": 0, "trsfr.layer.0.w": 6400, "trsfr.layer.1.w": 19200, "enc_img.swin.w": 32000, "fc_mtm.w": 51200, "emb_task": 60800}
+    ends = {"enc_txt.a": 6400, "trsfr.layer.0.w": 19200, "trsfr.layer.1.w": 32000, "enc_img.swin.w": 51200, "fc_mtm.w": 60800, "emb_task": n}
+    arena = types.SimpleNamespace(total=n, master=torch.full((n,), float(rank + 1)), grad=torch.zeros(n), names=names, listeners=[],
+                                  span=lambda ns: (min(offs[x] for x in ns), max(ends[x] for x in ns)),
                                   sync_half=lambda: synced.append(1))
     model = types.SimpleNamespace(arena=lambda: arena)
     red = ArenaReducer(model, bucket_mb=0.05)                 # ~13k-element buckets -> 5 buckets
@@ -31,6 +35,15 @@ def _worker(rank, world, port, q):
     arena.grad.copy_(local)
     red.finish()
     expect = sum(torch.randn(n, generator=torch.Generator().manual_seed(r)) for r in range(world))
+    ok &= bool(torch.allclose(arena.grad, expect, atol=1e-6))
+    # second step with the early (overlapped) exchange of the fusion-side ranges: nothing reduced twice, nothing missed
+    ok &= red.early_ranges == [(6400, 32000), (51200, 60800)]
+    arena.grad.copy_(local)
+    for f in arena.listeners:
+        f("fusion_grads_final")
+    mid = arena.grad.clone()
+    ok &= bool(torch.allclose(mid[6400:32000], expect[6400:32000], atol=1e-6)) and bool(torch.equal(mid[:6400], local[:6400]))
+    red.finish()
     ok &= bool(torch.allclose(arena.grad, expect, atol=1e-6))
     ok &= red.world == world
     q.put((rank, ok))

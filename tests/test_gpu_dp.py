@@ -45,12 +45,16 @@ def _worker(rank, world, port, q):
     agent.prepare_dist_model()
     assert agent.dp is not None and agent.dp.world == world
     w0 = m.arena().master.clone()
-    g_own = _rank_grads(rank, agent, m)
+    # reference: both ranks' local gradients computed in this process with the reducer detached
+    listeners, m.arena().listeners = m.arena().listeners, []
+    g_mine = _rank_grads(rank, agent, m)
+    g_other = _rank_grads(1 - rank, agent, m)
+    m.arena().listeners = listeners
+    # the real thing: backward (fusion-side ranges are all-reduced while the video backward still runs) + finish()
+    _rank_grads(rank, agent, m)
     agent.dp.finish()
     g_sum = m.arena().grad.clone()
-    # replay the other rank's batch locally (same weights after the broadcast) and compare
-    g_other = _rank_grads(1 - rank, agent, m)
-    rel = ((g_own + g_other) - g_sum).norm() / g_sum.norm()
+    rel = ((g_mine + g_other) - g_sum).norm() / g_sum.norm()
     m.arena().grad.copy_(g_sum)
     agent.optzr.step(max_norm=1.0, grad_div=float(world))
     torch.cuda.synchronize()
