@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                         if (key < N) { TokInfo t = win_token(a, prob, key); info = t.code | (t.region << 16); }
                     } else {
                         float add = 0.f;
-                        if (a.d.key_mask && key < N && a.d.key_mask[(long)prob * N + key] == 0) add = -INFINITY;
+                        if (key >= N || (a.d.key_mask && a.d.key_mask[(long)prob * N + key] == 0)) add = -INFINITY;
                         info = __float_as_int(add);
                     }
                     kinfo[row] = info;
@@ -160,12 +160,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(s[kt][r] - m_use); l_run += p[r]; }
                     if (MODE == 1 && a.d.dropout_p > 0.f) {
                         const float inv = 1.f / (1.f - a.d.dropout_p);
-                        const uint64_t base = ((uint64_t)(prob * a.d.heads + head) * (uint64_t)N + (uint64_t)q) * (uint64_t)N;
+                        const uint32_t base = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)q) * (uint32_t)N + (uint32_t)(kc0 + k0 + 4 * hi);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int key = kc0 + k0 + tile_row(r, hi);
-                            p[r] = lav_keep(a.d.seed, base + key, a.thresh) ? p[r] * inv : 0.f;
-                        }
+                        for (int r = 0; r < 16; ++r)
+                            p[r] = lav_keep(a.d.seed, base + (uint32_t)((r & 3) + 8 * (r >> 2)), a.thresh) ? p[r] * inv : 0.f;
                     }
 #pragma unroll
                     for (int sl = 0; sl < 2; ++sl) {
@@ -287,7 +285,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a, float* del
                         if (key < N) { TokInfo t = win_token(a, prob, key); info = t.code | (t.region << 16); }
                     } else {
                         float add = 0.f;
-                        if (a.d.key_mask && key < N && a.d.key_mask[(long)prob * N + key] == 0) add = -INFINITY;
+                        if (key >= N || (a.d.key_mask && a.d.key_mask[(long)prob * N + key] == 0)) add = -INFINITY;
                         info = __float_as_int(add);
                     }
                     kinfo[row] = info;
@@ -309,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a, float* del
                 }
                 float ds[16];
                 const float inv = (MODE == 1 && a.d.dropout_p > 0.f) ? 1.f / (1.f - a.d.dropout_p) : 1.f;
-                const uint64_t base = ((uint64_t)(prob * a.d.heads + head) * (uint64_t)N + (uint64_t)q) * (uint64_t)N;
+                const uint32_t base = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)q) * (uint32_t)N + (uint32_t)kc0;
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int kb = k0 + 8 * r4 + 4 * hi;
@@ -332,7 +330,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a, float* del
                         float p = valid ? fast_exp2(v - lse) : 0.f;
                         float g = dp[r];
                         if (MODE == 1 && a.d.dropout_p > 0.f)
-                            g = lav_keep(a.d.seed, base + (kc0 + kb + e), a.thresh) ? g * inv : 0.f;
+                            g = lav_keep(a.d.seed, base + (uint32_t)(kb + e), a.thresh) ? g * inv : 0.f;
                         const float dsv = p * (g - dl);
                         ds[r] = dsv;
                         if (MODE == 0 && valid) atomicAdd(&dtbl[bidx], dsv);
@@ -501,7 +499,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a, const flo
                         const float p = valid ? fast_exp2(v - ls[e]) : 0.f;
                         float g = dp[r], pdrop = p;
                         if (MODE == 1 && a.d.dropout_p > 0.f) {
-                            const uint64_t idx = ((uint64_t)(prob * a.d.heads + head) * (uint64_t)N + (uint64_t)q) * (uint64_t)N + (uint64_t)key;
+                            const uint32_t idx = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)q) * (uint32_t)N + (uint32_t)key;
                             const bool keep = lav_keep(a.d.seed, idx, a.thresh);
                             g = keep ? g * inv : 0.f;
                             pdrop = keep ? p * inv : 0.f;

@@ -77,10 +77,10 @@ __device__ __forceinline__ uint32_t lav_mix(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ bool lav_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
-    // one multiply-xorshift round per element (6 VALU ops): plenty for dropout masks, and the mask costs less than
-    // the softmax it is applied to (the 3-round version was 48 % of the fusion-attention forward)
-    uint32_t h = (uint32_t)idx * 0x9E3779B1u + seed + (uint32_t)(idx >> 32) * 0x85EBCA77u;
+__device__ __forceinline__ bool lav_keep(uint32_t seed, uint32_t idx, uint32_t thresh) {
+    // one multiply-xorshift round on a 32-bit element index (wrapping): 6 VALU ops.  The first version hashed a 64-bit
+    // index with three rounds and cost more than the softmax it masks (PMC: ~70 VALU instructions per score element).
+    uint32_t h = idx * 0x9E3779B1u + seed;
     h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
     return h >= thresh;                           // P(keep) = 1 - thresh / 2^32
 }

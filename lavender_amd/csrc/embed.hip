@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(int n, int X, int H
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 y[k] = (v[it][k] - mean) * rstd * gamma[col + k] + beta[col + k];
-                if (p > 0.f) y[k] = lav_keep(seed, (uint64_t)r * Hd + col + k, thresh) ? y[k] * inv : 0.f;
+                if (p > 0.f) y[k] = lav_keep(seed, (uint32_t)r * (uint32_t)Hd + (uint32_t)(col + k), thresh) ? y[k] * inv : 0.f;
             }
             *(uint4*)(out + r * Hd + col) = pack8(y);
         }
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(int n, int X, int H
             uint4 du = *(const uint4*)(dout + r * Hd + col); unpack8(du, d);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if (p > 0.f) d[k] = lav_keep(seed, (uint64_t)r * Hd + col + k, thresh) ? d[k] * inv : 0.f;
+                if (p > 0.f) d[k] = lav_keep(seed, (uint32_t)r * (uint32_t)Hd + (uint32_t)(col + k), thresh) ? d[k] * inv : 0.f;
                 const float xv = word[id * Hd + col + k] + pos[(long)xp * Hd + col + k] + type0[col + k];
                 xh[it][k] = (xv - mean) * rstd;
                 gy[it][k] = gamma[col + k] * d[k];

@@ -217,7 +217,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             const float inv = 1.0f / (1.0f - e.dropout_p);
 #pragma unroll
             for (int x = 0; x < 8; ++x)
-                v[x] = lav_keep(e.seed, (uint64_t)grow * (uint64_t)g.N + (uint64_t)(gcol + x), g.drop_thresh) ? v[x] * inv : 0.f;
+                v[x] = lav_keep(e.seed, (uint32_t)grow * (uint32_t)g.N + (uint32_t)(gcol + x), g.drop_thresh) ? v[x] * inv : 0.f;
         }
         if (e.row_scale) {
             const float s = e.row_scale[grow / e.rows_per_group];

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
                     for (int k = 0; k < 8; ++k) {
                         float t = o[k] * rs;
                         if (a.ex.dropout_p > 0.f)
-                            t = lav_keep(a.ex.seed, (uint64_t)row * (uint64_t)a.C + (uint64_t)(col + k), a.thresh) ? t * inv_keep : 0.f;
+                            t = lav_keep(a.ex.seed, (uint32_t)row * (uint32_t)a.C + (uint32_t)(col + k), a.thresh) ? t * inv_keep : 0.f;
                         o2[k] = t;
                         cs[it][k] += t;
                     }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void scale_mask_kernel(int rows, int C, const 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float t = v[k] * rs * gg[k];
-            if (p > 0.f) t = lav_keep(seed, (uint64_t)row * (uint64_t)C + (uint64_t)(col + k), thresh) ? t * inv : 0.f;
+            if (p > 0.f) t = lav_keep(seed, (uint32_t)row * (uint32_t)C + (uint32_t)(col + k), thresh) ? t * inv : 0.f;
             v[k] = t;
             cs[k] += t;
         }

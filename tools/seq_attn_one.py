@@ -1,0 +1,18 @@
+"""Runs the fusion-attention kernels a few times (for rocprofv3 --pmc)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lavender_amd import hip as K
+n, L, heads, p = 128, 282, 12, 0.1
+Hd = heads * 64
+qkv = torch.randn(n * L, 3 * Hd, device="cuda").bfloat16()
+km = torch.ones(n, L, dtype=torch.int32, device="cuda")
+att = K.Attn(1, heads, 64, n_seq=n, L=L, key_mask=km, dropout_p=p, seed=123)
+lse = torch.empty(att.lse_elems(), device="cuda")
+out = torch.empty(n * L, Hd, device="cuda", dtype=torch.bfloat16)
+dout = torch.randn(n * L, Hd, device="cuda").bfloat16()
+dqkv = torch.empty_like(qkv)
+for _ in range(3):
+    att.fwd(qkv, out, lse)
+    att.bwd(qkv, out, dout, lse, dqkv, None)
+torch.cuda.synchronize()
