@@ -42,7 +42,7 @@ int lav_abi_version(void);
  */
 typedef struct lav_gemm_epilogue {
     const float* bias;        /* [N] fp32 or NULL */
-    int act;                  /* 0 none, 1 exact (erf) GELU */
+    int act;                  /* 0 none, 1 exact (erf) GELU, 2 ReLU */
     void* preact;             /* bf16 [M, ldp]: receives z = alpha*acc+bias before the activation (or GELU'(z) when
                                  preact_is_grad), or NULL */
     long ldp;
@@ -61,7 +61,7 @@ typedef struct lav_gemm_epilogue {
     int k_rows_per_group;
     float* rowsum_a;          /* layout 2 only: fp32 [M] += alpha * sum_k A[k, m] -- the bias gradient sum(dy), fused
                                  into the weight-gradient GEMM on the matrix cores (no extra pass over dy) */
-    int preact_is_grad;       /* forward: store GELU'(z) instead of z (the backward then needs one multiply, no erf) */
+    int preact_is_grad;       /* forward: store act'(z) instead of z (the backward then needs one multiply, no erf) */
     int gelu_in_is_grad;      /* backward: gelu_in already holds GELU'(z) */
 } lav_gemm_epilogue;
 
@@ -206,6 +206,23 @@ int lav_gather_sum_rows(void* stream, int n_out, int C, const void* src, long ld
 int lav_cross_entropy_fwd_bwd(void* stream, int rows, int V, void* logits, long ld, const int64_t* labels,
                               float* loss_sum, float grad_scale, int write_grad /* 0: loss only, logits untouched */);
 int lav_scale_by_count(void* stream, long n_elems, void* x_bf16, const float* loss_sum, float gscale);
+/* same contract on FP32 logits with few classes (the (B, O) matching scores of the task-specific variant) */
+int lav_cross_entropy_f32_fwd_bwd(void* stream, int rows, int V, float* logits, long ld, const int64_t* labels,
+                                  float* loss_sum, float grad_scale, int write_grad);
+
+/* ---------------------------------------------------------------------------------------------
+ * Video-text matching score head of the task-specific pre-training variant: the last layer of
+ * self.fc = Sequential(Dropout, Linear(H,2H), ReLU, Linear(2H,1)) (main_pretrain_task_specific.py:128-133)
+ * and "out_vtm = fc(out[:, Lv]).view(B, O) / temp" (:168-170).  Dropout and Linear+ReLU run through
+ * lav_scale_mask_rows / lav_gemm_bf16 (act = 2); these two entries do the (n, F) x (F,) row dots.
+ *   fwd: logits[r / O][r % O] = (h[r,:] . w + bias[0]) * inv_temp        (logits: FP32 (n/O, ld), ld >= O)
+ *   bwd: dz = dlogits (fp32) * inv_temp; dh[r,:] = dz_r * w * act_grad[r,:] (act_grad = ReLU'(z1) stored by the GEMM,
+ *        or NULL); dw += sum_r dz_r h[r,:]; db[0] += sum_r dz_r      (fp32 atomics into the gradient arena) */
+int lav_pair_score_fwd(void* stream, int n, int F, const void* h, long ldh, const void* w_bf16, const float* bias,
+                       float inv_temp, int O, void* logits, long ld);
+int lav_pair_score_bwd(void* stream, int n, int F, const void* dlogits, long ld, int O, float inv_temp, const void* h,
+                       long ldh, const void* act_grad, long ldg, const void* w_bf16, void* dh, long lddh, float* dw,
+                       float* db);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer over the flat parameter arena (Agent_Base.backward_step, agent.py:241-250: unscale/clip by

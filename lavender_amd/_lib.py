@@ -71,6 +71,9 @@ _SIGS = {
     "lav_gather_sum_rows": (i32, [vp, i32, i32, vp, i64, vp, vp, vp, i64]),
     "lav_cross_entropy_fwd_bwd": (i32, [vp, i32, i32, vp, i64, vp, vp, f32, i32]),
     "lav_scale_by_count": (i32, [vp, i64, vp, vp, f32]),
+    "lav_cross_entropy_f32_fwd_bwd": (i32, [vp, i32, i32, vp, i64, vp, vp, f32, i32]),
+    "lav_pair_score_fwd": (i32, [vp, i32, i32, vp, i64, vp, vp, f32, i32, vp, i64]),
+    "lav_pair_score_bwd": (i32, [vp, i32, i32, vp, i64, i32, f32, vp, i64, vp, i64, vp, vp, i64, vp, vp]),
     "lav_sumsq_f32": (i32, [vp, i64, vp, vp]),
     "lav_adamw_step": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, P(f32), P(f32), f32, f32, f32, i32, vp, f32, f32]),
     "lav_cast_f32_to_bf16": (i32, [vp, i64, vp, vp]),

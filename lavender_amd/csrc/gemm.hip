@@ -200,6 +200,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
                 for (int x = 0; x < 8; ++x) v[x] = gelu_f(v[x]);
             }
         }
+        if (e.act == 2) {                                  // ReLU (score head, main_pretrain_task_specific.py:131)
+            if (e.preact && e.preact_is_grad) {
+                float gp[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) gp[x] = v[x] > 0.f ? 1.f : 0.f;
+                bf16_t* p = (bf16_t*)e.preact + (long)grow * e.ldp + gcol;
+                if (full) *(uint4*)p = pack8(gp);
+                else for (int x = 0; x < ncols; ++x) p[x] = f2bf(gp[x]);
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) v[x] = fmaxf(v[x], 0.f);
+        }
         if (e.gelu_in) {
             const bf16_t* p = (const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol;
             float h[8];

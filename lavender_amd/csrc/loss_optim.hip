@@ -72,6 +72,42 @@ extern "C" int lav_cross_entropy_fwd_bwd(void* stream, int rows, int V, void* lo
     return lav_check_launch("lav_cross_entropy_fwd_bwd");
 }
 
+// fp32 logits, few classes (the (B, O) video-text matching scores): one wave per row, same contract as ce_kernel
+__global__ __launch_bounds__(256) void ce_f32_kernel(int rows, int V, float* logits, long ld, const int64_t* labels, float* loss_sum,
+                                                    float grad_scale, int write_grad) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* x = logits + (long)row * ld;
+    const long label = labels[row];
+    if (label < 0) {
+        if (write_grad)
+            for (int c = lane; c < V; c += 64) x[c] = 0.f;
+        return;
+    }
+    float m = -INFINITY;
+    for (int c = lane; c < V; c += 64) m = fmaxf(m, x[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < V; c += 64) s += __expf(x[c] - m);
+    s = wave_sum(s);
+    const float lse = m + __logf(s);
+    const float xl = x[label];
+    if (lane == 0) {
+        atomicAdd(loss_sum, lse - xl);
+        atomicAdd(loss_sum + 1, 1.0f);
+    }
+    if (!write_grad) return;
+    for (int c = lane; c < V; c += 64) x[c] = (__expf(x[c] - lse) - (c == label ? 1.f : 0.f)) * grad_scale;
+}
+
+extern "C" int lav_cross_entropy_f32_fwd_bwd(void* stream, int rows, int V, float* logits, long ld, const int64_t* labels,
+                                             float* loss_sum, float grad_scale, int write_grad) {
+    LAV_REQUIRE(rows > 0 && V > 0 && ld >= V && logits && labels && loss_sum, "lav_cross_entropy_f32_fwd_bwd: bad arguments");
+    hipLaunchKernelGGL(ce_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, V, logits, ld, labels, loss_sum,
+                       grad_scale, write_grad);
+    return lav_check_launch("lav_cross_entropy_f32_fwd_bwd");
+}
+
 __global__ __launch_bounds__(256) void scale_bf16_kernel(long n8, bf16_t* x, const float* cnt, float gscale) {
     const float s = cnt ? gscale / fmaxf(cnt[1], 1.f) : gscale;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
@@ -90,6 +126,77 @@ extern "C" int lav_scale_by_count(void* stream, long n_elems, void* x_bf16, cons
     int grid = (int)((n8 + 255) / 256 > 8192 ? 8192 : (n8 + 255) / 256);
     hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n8, (bf16_t*)x_bf16, loss_sum, gscale);
     return lav_check_launch("lav_scale_by_count");
+}
+
+// ---- video-text matching score head (main_pretrain_task_specific.py:128-133,168-170) ------------------
+// last layer of self.fc = Linear(2H, 1): one score per (video, text) pair, divided by the temperature and laid
+// out as the (B, O) logit matrix the cross-entropy consumes.  One wave per pair row.
+__global__ __launch_bounds__(256) void pair_score_fwd_kernel(int n, int F, const bf16_t* __restrict__ h, long ldh,
+                                                            const bf16_t* __restrict__ w, const float* __restrict__ b,
+                                                            float inv_temp, int O, float* __restrict__ logits, long ld) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const bf16_t* x = h + (long)row * ldh;
+    float s = 0.f;
+    for (int c = lane; c < F / 8; c += 64) {
+        float a[8], ww[8];
+        unpack8(*(const uint4*)(x + c * 8), a);
+        unpack8(*(const uint4*)(w + c * 8), ww);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += a[k] * ww[k];
+    }
+    s = wave_sum(s);
+    if (lane == 0) logits[(long)(row / O) * ld + row % O] = (s + b[0]) * inv_temp;
+}
+
+// backward of the score head: dz = dlogits * inv_temp; dh = dz * w * act'(z1) (act' stored by the first GEMM);
+// dw += sum_r dz_r h_r; db += sum_r dz_r.  One block per 32 pair rows, thread t owns columns 8t..8t+7.
+__global__ __launch_bounds__(256) void pair_score_bwd_kernel(int n, int F, const float* __restrict__ dlogits, long ld, int O,
+                                                            float inv_temp, const bf16_t* __restrict__ h, long ldh,
+                                                            const bf16_t* __restrict__ act_grad, long ldg,
+                                                            const bf16_t* __restrict__ w, bf16_t* __restrict__ dh, long lddh,
+                                                            float* __restrict__ dw, float* __restrict__ db) {
+    const int r0 = blockIdx.x * 32, r1 = min(n, r0 + 32);
+    float dbs = 0.f;
+    for (int c = threadIdx.x; c < F / 8; c += 256) {
+        float ww[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unpack8(*(const uint4*)(w + c * 8), ww);
+        for (int r = r0; r < r1; ++r) {
+            const float dz = dlogits[(long)(r / O) * ld + r % O] * inv_temp;
+            float a[8], g[8], o[8];
+            unpack8(*(const uint4*)(h + (long)r * ldh + c * 8), a);
+            if (act_grad) unpack8(*(const uint4*)(act_grad + (long)r * ldg + c * 8), g);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                acc[k] += dz * a[k];
+                o[k] = dz * ww[k] * (act_grad ? g[k] : 1.f);
+            }
+            *(uint4*)(dh + (long)r * lddh + c * 8) = pack8(o);
+            if (c == 0) dbs += dz;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(dw + c * 8 + k, acc[k]);
+    }
+    if (threadIdx.x == 0) atomicAdd(db, dbs);
+}
+
+extern "C" int lav_pair_score_fwd(void* stream, int n, int F, const void* h, long ldh, const void* w_bf16, const float* bias,
+                                  float inv_temp, int O, void* logits, long ld) {
+    LAV_REQUIRE(n > 0 && F > 0 && F % 8 == 0 && O > 0 && n % O == 0 && ld >= O && ldh % 8 == 0 && h && w_bf16 && bias && logits,
+                "lav_pair_score_fwd: bad arguments");
+    hipLaunchKernelGGL(pair_score_fwd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, n, F, (const bf16_t*)h, ldh,
+                       (const bf16_t*)w_bf16, bias, inv_temp, O, (float*)logits, ld);
+    return lav_check_launch("lav_pair_score_fwd");
+}
+
+extern "C" int lav_pair_score_bwd(void* stream, int n, int F, const void* dlogits, long ld, int O, float inv_temp, const void* h,
+                                  long ldh, const void* act_grad, long ldg, const void* w_bf16, void* dh, long lddh, float* dw,
+                                  float* db) {
+    LAV_REQUIRE(n > 0 && F > 0 && F % 8 == 0 && O > 0 && n % O == 0 && ld >= O && ldh % 8 == 0 && lddh % 8 == 0 &&
+                (!act_grad || ldg % 8 == 0) && dlogits && h && w_bf16 && dh && dw && db, "lav_pair_score_bwd: bad arguments");
+    hipLaunchKernelGGL(pair_score_bwd_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, n, F, (const float*)dlogits, ld,
+                       O, inv_temp, (const bf16_t*)h, ldh, (const bf16_t*)act_grad, ldg, (const bf16_t*)w_bf16, (bf16_t*)dh, lddh, dw, db);
+    return lav_check_launch("lav_pair_score_bwd");
 }
 
 // ---- optimizer over the flat arena ------------------------------------------------------------------

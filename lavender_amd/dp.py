@@ -36,11 +36,11 @@ class ArenaReducer:
 
     @staticmethod
     def _fusion_ranges(a):
-        """Arena ranges whose gradients are final once the backward leaves the fusion side: trsfr.* and fc_mtm.*"""
+        """Arena ranges whose gradients are final once the backward leaves the fusion side: trsfr.*, fc.* and fc_mtm.*"""
         if not hasattr(a, "span") or not hasattr(a, "names"):
             return []
         out = []
-        for pre in ("trsfr.", "fc_mtm."):
+        for pre in ("trsfr.", "fc.", "fc_mtm."):
             names = [n for n in a.names if n.startswith(pre)]
             if names:
                 out.append(a.span(names))

@@ -414,6 +414,48 @@ class MLMHeadFn(torch.autograd.Function):
         return None, dx.view(ctx.shp), None
 
 
+class ScoreHeadFn(torch.autograd.Function):
+    """self.fc of the task-specific pre-training model (main_pretrain_task_specific.py:128-133) applied to the
+    first text position, reshaped to (B, O) and divided by the temperature (:168-170)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, fc, O, inv_temp, dropout_p):
+        n, Hd = x.shape
+        lin1, lin2 = fc[1], fc[3]
+        F = lin1.weight.shape[0]
+        keep = _keep(ctx)
+        x = x.contiguous()
+        seed = K.next_seed()
+        xd = x
+        if dropout_p > 0:
+            xd = torch.empty_like(x)
+            K.scale_mask_rows(x, n, Hd, out=xd, dropout_p=dropout_p, seed=seed)
+        act_grad = torch.empty((n, F), dtype=bf16, device=x.device) if keep else None
+        h = K.gemm(0, xd, W16(lin1.weight), n, F, Hd, bias=lin1.bias.data, act=2, preact=act_grad, preact_is_grad=True)
+        logits = K.pair_score_fwd(h, n, F, W16(lin2.weight).view(F), lin2.bias.data, inv_temp, O)
+        if keep:
+            ctx.fc, ctx.cfg = fc, (O, inv_temp, dropout_p, seed)
+            ctx.save_for_backward(xd, h, act_grad)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        fc, (O, inv_temp, dropout_p, seed) = ctx.fc, ctx.cfg
+        xd, h, act_grad = ctx.saved_tensors
+        lin1, lin2 = fc[1], fc[3]
+        n, Hd = xd.shape
+        F = lin1.weight.shape[0]
+        assert dlogits.stride(-1) == 1
+        dz1 = K.pair_score_bwd(dlogits, n, F, O, inv_temp, h, act_grad, W16(lin2.weight).view(F), G(lin2.weight).view(F),
+                               G(lin2.bias))
+        K.colsum(dz1, n, F, G(lin1.bias))
+        K.gemm(2, dz1, xd, F, Hd, n, out=G(lin1.weight), accumulate=True, splits=1)
+        dx = K.gemm(1, dz1, W16(lin1.weight), n, Hd, F)
+        if dropout_p > 0:
+            K.scale_mask_rows(dx, n, Hd, out=dx, dropout_p=dropout_p, seed=seed)
+        return None, dx, None, None, None, None
+
+
 class CrossEntropyFn(torch.autograd.Function):
     """CrossEntropyLoss(ignore_index=-1) (agent.py:72).  Training: the logits buffer is consumed -- it is
     overwritten in place with d(loss)/d(logits)."""
@@ -421,14 +463,16 @@ class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, count):
         V = logits.shape[-1]
-        assert logits.dim() == 2 and logits.stride(-1) == 1 and logits.stride(0) % 8 == 0, \
-            "logits must be a (rows, V) view of a row-padded bf16 buffer (as produced by the MLM head)"
+        f32 = logits.dtype == torch.float32
+        assert logits.dim() == 2 and logits.stride(-1) == 1 and (f32 or logits.stride(0) % 8 == 0), \
+            "logits must be a (rows, V) view of a row-padded bf16 buffer (as produced by the MLM head) or fp32 scores"
         labels = labels.contiguous()
         acc = torch.zeros(2, dtype=torch.float32, device=logits.device)
         train = ctx.needs_input_grad[0]
         scale = (1.0 / max(count, 1)) if count is not None else 1.0
         K.cross_entropy(logits, V, labels, acc, scale, train)
         if train and count is None:
+            assert not f32, "fp32 score logits: pass the labelled-row count"
             n = logits.shape[0] * logits.stride(0)
             K.scale_by_count(logits, n, acc, 1.0)
         ctx.grad_buf = logits if train else None
@@ -445,7 +489,10 @@ class CrossEntropyFn(torch.autograd.Function):
         if not CrossEntropyFn.assume_unit_grad:
             gv = float(g)
             if gv != 1.0:
-                K.scale_by_count(buf, buf.shape[0] * buf.stride(0), None, gv)
+                if buf.dtype == torch.float32:
+                    buf.mul_(gv)
+                else:
+                    K.scale_by_count(buf, buf.shape[0] * buf.stride(0), None, gv)
         return buf, None, None
 
 

@@ -271,12 +271,32 @@ def gather_sum_rows(src, start, lst, n_out, Cn):
 
 def cross_entropy(logits2d, V, labels, loss_sum, grad_scale, write_grad):
     rows = logits2d.shape[0]
+    if logits2d.dtype == torch.float32:
+        L.check(L.lib.lav_cross_entropy_f32_fwd_bwd(_s(), rows, V, _p(logits2d), _ld(logits2d), _p(labels), _p(loss_sum),
+                                                    float(grad_scale), int(write_grad)), "lav_cross_entropy_f32_fwd_bwd")
+        return
     L.check(L.lib.lav_cross_entropy_fwd_bwd(_s(), rows, V, _p(logits2d), _ld(logits2d), _p(labels), _p(loss_sum),
                                             float(grad_scale), int(write_grad)), "lav_cross_entropy_fwd_bwd")
 
 
 def scale_by_count(x, n_elems, loss_sum, gscale):
     L.check(L.lib.lav_scale_by_count(_s(), int(n_elems), _p(x), _p(loss_sum), float(gscale)), "lav_scale_by_count")
+
+
+def pair_score_fwd(h, n, F, w16, bias, inv_temp, O):
+    """(n, F) hidden rows -> (n // O, O) fp32 logits."""
+    buf = torch.empty((n // O, O), dtype=torch.float32, device=h.device)
+    L.check(L.lib.lav_pair_score_fwd(_s(), n, F, _p(h), _ld(h), _p(w16), _p(bias), float(inv_temp), O, _p(buf), O),
+            "lav_pair_score_fwd")
+    return buf
+
+
+def pair_score_bwd(dlogits, n, F, O, inv_temp, h, act_grad, w16, dw, db):
+    dh = torch.empty((n, F), dtype=bf16, device=h.device)
+    L.check(L.lib.lav_pair_score_bwd(_s(), n, F, _p(dlogits), dlogits.stride(0), O, float(inv_temp), _p(h), _ld(h),
+                                     _p(act_grad), _ld(act_grad) if act_grad is not None else 0, _p(w16), _p(dh), F,
+                                     _p(dw), _p(db)), "lav_pair_score_bwd")
+    return dh
 
 
 def sumsq(g, n, out):

@@ -367,6 +367,52 @@ def pretrain_loss(out):
     return l_mtm, l_vtm
 
 
+def score_head(P, x):
+    """self.fc of LAVENDER_Pretrain, main_pretrain_task_specific.py:128-133 (eval: Dropout is the identity):
+    Linear(H, 2H) -> ReLU -> Linear(2H, 1)."""
+    return _lin(torch.relu(_lin(x, P, "fc.1")), P, "fc.3")
+
+
+def pretrain_ts_forward(P, batch, size, heads, temp, droppath=None):
+    """LAVENDER_Pretrain.forward, main_pretrain_task_specific.py:139-177 (eval-mode arithmetic)."""
+    img, txt, mask = batch["img"], batch["txt"], batch["mask"]
+    B, X = txt.shape
+    O = min(B, 4)
+    f_img, m_img = enc_video(P, img, size, droppath)
+    f_txt = enc_txt(P, txt)
+    Lv = f_img.shape[1]
+    out = go_cross(P, f_img, m_img, f_txt, mask, heads)
+    out_mtm = mlm_head(P, out[:, Lv:])
+    vi, ti, _ = vtm_pairs(B, O)
+    out = go_cross(P, f_img[vi], m_img[vi], f_txt[ti], mask[ti], heads)
+    out_vtm = score_head(P, out[:, Lv, :]).squeeze().view(B, O) / temp
+    return dict(out_mtm=out_mtm, out_vtm=out_vtm, ans_vtm=torch.zeros(B, dtype=torch.long), ans_mtm=batch.get("ans_mtm"))
+
+
+def pretrain_ts_loss(out):
+    """Agent_Pretrain.step, main_pretrain_task_specific.py:222-229."""
+    V = out["out_mtm"].shape[-1]
+    l_mtm = F.cross_entropy(out["out_mtm"].reshape(-1, V), out["ans_mtm"].reshape(-1), ignore_index=-1)
+    l_vtm = F.cross_entropy(out["out_vtm"], out["ans_vtm"], ignore_index=-1)
+    return l_mtm, l_vtm
+
+
+def retrieval_forward(P, batch, size, heads, ids=SPECIAL):
+    """LAVENDER_Retrieval_MLM.forward, main_retrieval_mlm.py:50-91: all B x B (video i, text j) pairs, i outer."""
+    img, txt, mask, vid = batch["img"], batch["txt"], batch["mask"], list(batch["vid"])
+    B, X = txt.shape
+    f_img, m_img = enc_video(P, img, size)
+    f_txt = enc_txt(P, txt)
+    Lv = f_img.shape[1]
+    vi = np.repeat(np.arange(B), B)
+    ti = np.tile(np.arange(B), B)
+    out = go_cross(P, f_img[vi], m_img[vi], f_txt[ti], mask[ti], heads)
+    out = mlm_head(P, out[:, Lv:])
+    ans = torch.full((B * B, X), -1, dtype=torch.long)
+    ans[:, -1] = torch.tensor([ids["true"] if vid[i] == vid[j] else ids["false"] for i, j in zip(vi, ti)])
+    return out, ans
+
+
 # --------------------------------------------------------------------------
 # optimizer-side host logic
 # --------------------------------------------------------------------------

@@ -158,3 +158,73 @@ def test_swin_shapes_pad_branches(golden_dir):
         x = torch.randn(1, 3, T, S, S, generator=torch.Generator().manual_seed(3))
         y = R.swin_forward(P, "enc_img.swin", x, "micro")
         np.testing.assert_allclose(sub(y, 2048), g[f"T{T}_S{S}_sub"], atol=2e-5)
+
+
+def _check_grads(P, g):
+    ref = dict(zip(g["grad_norm_keys"].tolist(), g["grad_norm_vals"].tolist()))
+    for k, v in ref.items():
+        if v < 0:
+            assert P[k].grad is None, k
+        else:
+            assert abs(P[k].grad.double().norm().item() - v) <= 1e-4 * v + 2e-6, k   # fc.3.bias: exact value 0
+    for k in g.files:
+        if k.startswith("grad_sub::"):
+            np.testing.assert_allclose(sub(P[k[10:]].grad, 2048), g[k], atol=2e-6, rtol=1e-3)
+
+
+def _variant_params(bert, swin, extra=()):
+    bc = BERT_CFGS[bert]
+    P = R.filled_params(swin, hidden=bc["hidden"], layers=bc["layers"], ffn=bc["ffn"], vocab=bc["vocab"])
+    for k, shp in extra:
+        P[k] = R.fill_tensor(k, shp)
+    for v in P.values():
+        v.requires_grad_(True)
+    return P, bc
+
+
+def test_task_specific_variant(golden_dir):
+    """LAVENDER_Pretrain (main_pretrain_task_specific.py:124-177): MLM logits + (B, O) matching scores, losses, grads."""
+    g = _load(golden_dir, "ts_micro_b5")
+    swin, bert, B, S, heads, temp = g["meta"].tolist()
+    B, heads, temp = int(B), int(heads), float(temp)
+    H = BERT_CFGS[bert]["hidden"]
+    P, bc = _variant_params(bert, swin, [("fc.1.weight", (2 * H, H)), ("fc.1.bias", (2 * H,)), ("fc.3.weight", (1, 2 * H)),
+                                         ("fc.3.bias", (1,))])
+    P.pop("emb_task")                                       # this variant has no task-token table
+    assert set(g["keys"].tolist()) - set(P) <= {"fc_mtm.predictions.decoder.bias"} | {k for k in g["keys"].tolist() if "relative_position_index" in k or "position_ids" in k}
+    batch = make_batch(B, vocab=bc["vocab"])
+    torch.manual_seed(88)
+    batch["txt"], batch["ans_mtm"] = R.masking(batch["txt"])
+    assert (batch["txt"].numpy() == g["txt"]).all() and (batch["ans_mtm"].numpy() == g["ans_mtm"]).all()
+    np.random.seed(88)
+    out = R.pretrain_ts_forward(P, batch, swin, heads, temp)
+    cols = torch.from_numpy(g["cols"])
+    np.testing.assert_allclose(out["out_mtm"][:, :, cols].detach().numpy(), g["out_mtm_cols"], atol=1e-5)
+    np.testing.assert_allclose(out["out_vtm"].detach().numpy(), g["out_vtm"], atol=2e-5)
+    assert (out["ans_vtm"].numpy() == g["ans_vtm"]).all()
+    l_mtm, l_vtm = R.pretrain_ts_loss(out)
+    np.testing.assert_allclose([l_mtm.item(), l_vtm.item()], g["loss"], atol=1e-5)
+    (l_mtm + l_vtm).backward()
+    _check_grads(P, g)
+
+
+def test_retrieval_variant(golden_dir):
+    """LAVENDER_Retrieval_MLM (main_retrieval_mlm.py:50-91): B x B pair order, labels from vid equality, logits, grads."""
+    g = _load(golden_dir, "retr_micro_b3")
+    swin, bert, B, S, heads = g["meta"].tolist()
+    B, heads = int(B), int(heads)
+    P, bc = _variant_params(bert, swin)
+    batch = make_batch(B, vocab=bc["vocab"], seed=4)
+    assert (batch["txt"].numpy() == g["txt"]).all()
+    batch["vid"] = g["vid"].tolist()
+    out, ans = R.retrieval_forward(P, batch, swin, heads)
+    assert (ans.numpy() == g["ans"]).all()
+    assert (ans[:, -1].view(B, B).numpy() == np.where(np.equal.outer(g["vid"], g["vid"]), 2995, 6270)).all()
+    cols = torch.from_numpy(g["cols"])
+    np.testing.assert_allclose(out[:, :, cols].detach().numpy(), g["out_cols"], atol=1e-5)
+    np.testing.assert_allclose(torch.logsumexp(out, -1).detach().numpy(), g["out_lse"], atol=1e-5)
+    ls = torch.nn.functional.cross_entropy(out.flatten(0, 1), ans.flatten(), ignore_index=-1)
+    np.testing.assert_allclose(ls.item(), g["loss"][0], atol=1e-5)
+    ls.backward()
+    P["emb_task"].grad = None
+    _check_grads(P, g)
