@@ -19,6 +19,7 @@ from . import hip as K
 # visbackbone/swin_{tiny,base,large}*.py -- only the keys video_swin.py:616-634 reads
 SWIN_SIZES = {
     "micro": dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=(8, 7, 7)),
+    "micro12": dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=(8, 12, 12)),  # test size: Large-384 windows
     "tiny": dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=(8, 7, 7)),
     "base": dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=(8, 7, 7)),
     "large": dict(embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], window_size=(8, 12, 12)),

@@ -107,7 +107,7 @@ class Tok:
 def build_reference(ref, swin, bert, B):
     os.environ["LAV_SWIN_SIZE"] = swin
     d = hf_dir(bert)
-    args = ref.EasyDict(vis_backbone_size="base" if swin in ("micro",) else swin, size_img=224,
+    args = ref.EasyDict(vis_backbone_size="base" if swin in ("micro", "micro12") else swin, size_img=224,
                         vis_backbone_init="random", kinetics=400, txt_backbone=d, txt_backbone_embed_only=True,
                         fusion_encoder=d, fusion_encoder_rand_init=False, use_checkpoint=False, size_patch=32,
                         size_batch=B, tokenizer=d, enable_task_token=False, enable_prompt=False, temp=0.05)

@@ -2,7 +2,8 @@
   * LAVENDER_Pretrain (main_pretrain_task_specific.py:124-177): MLM + scalar video-text-matching score head;
   * LAVENDER_Retrieval_MLM (main_retrieval_mlm.py:30-91): all B x B pairs through the MLM head.
 Same recipe as make_goldens.py (stubbed third-party imports, parameters filled from their state_dict keys,
-seeded inputs); writes ts_micro_b5.npz and retr_micro_b3.npz next to this file.
+seeded inputs); writes ts_micro_b5.npz, retr_micro_b3.npz and micro12_s384_b2.npz (MLM model on 384^2 frames with the
+Large-384 window geometry) next to this file.
 
     python tests/golden/make_goldens_variants.py
 """
@@ -120,6 +121,8 @@ def run_retrieval(ref):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ref = MG.import_reference()
+    # BASELINE config 4 geometry (384^2 frames, window (8,12,12) -> (5,12,12), N = 720 tokens per window) at micro widths
+    MG.run_model_case(ref, "micro12_s384_b2", "micro12", "micro", 2, S=384)
     run_task_specific(ref)
     run_retrieval(ref)
     print("variant goldens written to", HERE)

@@ -30,13 +30,15 @@ def _to_cuda(batch):
     return {k: v.cuda() for k, v in batch.items()}
 
 
-@pytest.mark.parametrize("case", ["micro_b2", "micro_b5"])
+@pytest.mark.parametrize("case", ["micro_b2", "micro_b5", "micro12_s384_b2"])
 def test_forward_matches_oracle_and_golden(golden_dir, case):
+    """micro12_s384_b2 = BASELINE config 4 geometry: 384^2 frames, (5,12,12) windows of 720 tokens (generic window
+    attention kernels), fusion sequences of 757 tokens."""
     from tests.helpers import build_filled_model
     g = np.load(os.path.join(golden_dir, case + ".npz"))
     swin, bert, B, S, heads = g["meta"].tolist()
     B = int(B)
-    R, P, batch, bc = _oracle_case(swin, bert, B)
+    R, P, batch, bc = _oracle_case(swin, bert, B, S=int(S))
     m = build_filled_model(swin, bert, B).eval()
     taps = {}
     with torch.no_grad():
@@ -60,18 +62,23 @@ def test_forward_matches_oracle_and_golden(golden_dir, case):
         d = (a - b).abs()
         agree = (a.argmax(-1) == b.argmax(-1)).float().mean().item()
         print(key, "max", d.max().item(), "mean", d.mean().item(), "argmax agree", agree)
-        assert d.max() < 3e-2 and d.mean() < 5e-3 and agree >= 0.97
+        assert d.max() < 3e-2 and d.mean() < 5e-3 and agree >= 0.9
+        # wherever the argmax differs, the oracle's own top-1 margin over our choice is inside the logit tolerance
+        # (near-ties of the key-filled weights), i.e. no disagreement is a real one
+        margin = b.max(-1).values - b.gather(-1, a.argmax(-1, keepdim=True)).squeeze(-1)
+        assert margin.max() < 3e-2, margin.max().item()
         cols = torch.from_numpy(g["cols"])
         np.testing.assert_allclose(a[:, :, cols].numpy(), g[key + "_cols"], atol=3e-2)
 
 
-def test_loss_and_gradients_match_oracle(golden_dir):
+@pytest.mark.parametrize("case", ["micro_b2", "micro12_s384_b2"])
+def test_loss_and_gradients_match_oracle(golden_dir, case):
     from tests.helpers import build_filled_model
     from lavender_amd.agent import CrossEntropyIgnore
-    g = np.load(os.path.join(golden_dir, "micro_b2.npz"))
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
     swin, bert, B, S, heads = g["meta"].tolist()
     B = int(B)
-    R, P, batch, bc = _oracle_case(swin, bert, B)
+    R, P, batch, bc = _oracle_case(swin, bert, B, S=int(S))
     for v in P.values():
         v.requires_grad_(True)
     np.random.seed(88)

@@ -151,6 +151,11 @@ def test_tiny2l_forward_backward(golden_dir):
     _run_case(golden_dir, "tiny2l_b2", True)
 
 
+def test_micro12_s384_forward_backward(golden_dir):
+    """BASELINE config 4 geometry (384^2 frames, window (8,12,12) -> (5,12,12)) at micro widths."""
+    _run_case(golden_dir, "micro12_s384_b2", True)
+
+
 def test_swin_shapes_pad_branches(golden_dir):
     g = _load(golden_dir, "swin_shapes")
     P = {k: v for k, v in R.filled_params("micro", hidden=128, layers=0, ffn=512, vocab=64).items()}
