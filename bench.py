@@ -52,7 +52,7 @@ def synth_batch(B, T, S, X, rank, device):
     img = torch.randn(B, T, 3, S, S, generator=g)
     txt = torch.zeros(B, X, dtype=torch.long)
     for b in range(B):
-        k = int(torch.randint(6, 28, (1,), generator=g))
+        k = int(torch.randint(6, min(28, X - 3), (1,), generator=g))
         txt[b, 0] = 101
         txt[b, 1:1 + k] = torch.randint(1000, 30000, (k,), generator=g)
         txt[b, 1 + k] = 102
@@ -109,8 +109,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--size", default="base")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 32 (cfg2), 8 (cfg4, cfg5)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
+                    help="BASELINE.json configs: cfg2 = headline (Swin-B 224, pretrain MLM); cfg4 = Swin-L 384^2 pretrain; "
+                         "cfg5 = retrieval B x B pairing, 26 text tokens.  The driver's contract line is cfg2 (default).")
+    ap.add_argument("--size", default=None)
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -135,7 +138,11 @@ def main():
     from lavender_amd.args import EasyDict
     from lavender_amd.dist import set_seed
 
-    B, T, S, X = a.batch, 5, 224, 32
+    wl = {"cfg2": dict(size="base", S=224, X=32, B=32), "cfg4": dict(size="large", S=384, X=32, B=8),
+          "cfg5": dict(size="base", S=224, X=26, B=8)}[a.workload]
+    a.size = a.size or wl["size"]
+    B, T, S, X = a.batch or wl["B"], 5, wl["S"], wl["X"]
+    retrieval = a.workload == "cfg5"
     cfg = dict(num_hidden_layers=a.layers)
     args = EasyDict(vis_backbone_size=a.size, size_img=S, vis_backbone_init="random", kinetics=600, txt_backbone=cfg,
                     txt_backbone_embed_only=True, fusion_encoder=cfg, fusion_encoder_rand_init=True, use_checkpoint=False,
@@ -151,9 +158,9 @@ def main():
             return [self.ids[t] for t in toks]
 
     set_seed(88)
-    model = LA.LAVENDER_Pretrain_MLM(args, Tok()).cuda()
+    model = (LA.LAVENDER_Retrieval_MLM if retrieval else LA.LAVENDER_Pretrain_MLM)(args, Tok()).cuda()
     model.arena()
-    agent = LA.Agent_Pretrain_MLM(args, model)
+    agent = (LA.Agent_Retrieval_MLM if retrieval else LA.Agent_Pretrain_MLM)(args, model)
     agent.prepare_dist_model()
     nparam = sum(p.numel() for p in model.parameters())
 
@@ -163,11 +170,16 @@ def main():
     torch.manual_seed(88)
     for i in range(nb):
         b = synth_batch(B, T, S, X, rank * 7 + i, "cuda")
-        b.update(agent.masking(b["txt"], b["mask"]))
+        if retrieval:
+            b["vid"] = list(range(B))
+        else:
+            b.update(agent.masking(b["txt"], b["mask"]))
         batches.append(agent.prepare_batch(b))
     np.random.seed(88)
 
     def run_step(i):
+        if retrieval:
+            return {"mtm": agent.step(batches[i % nb], True)}
         return agent.step(batches[i % nb], True, sync=False)
 
     def barrier():
@@ -227,11 +239,14 @@ def main():
         ms = dt / a.steps * 1e3
         value = world * B * a.steps / dt
         fstep = 3.0 * flops_per_sample(**{"base": {}, "tiny": dict(E=96, depths=(2, 2, 6, 2)),
-                                          "large": dict(E=192)}.get(a.size, {}), layers=a.layers)
+                                          "large": dict(E=192, win=(8, 12, 12))}.get(a.size, {}), layers=a.layers, S=S, X=X,
+                                       n_seq=B if retrieval else 1 + min(B, 4))
+        what = {"cfg2": "cfg2: ", "cfg4": "cfg4 (parity/bench side case): ", "cfg5": "cfg5 retrieval B x B pairing (side case): "}[a.workload]
         out = {"metric": "video-text samples/sec (node) pretrain step, Swin-B 5x224^2 + 32-tok", "value": round(value, 2),
                "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"cfg2: Swin-{a.size}-K600-22k + {a.layers}-layer fusion + MLM head, main_pretrain_mlm path, "
+               "config": {"workload": f"{what}Swin-{a.size}-K600-22k + {a.layers}-layer fusion + MLM head, "
+                                      f"{'main_retrieval_mlm' if retrieval else 'main_pretrain_mlm'} path, "
                                       f"fwd+bwd+clip+AdamW, dropout 0.1 / drop-path 0.2 on",
                           "per_gpu_batch": B, "global_batch": B * world, "frames": T, "size_img": S, "size_txt": X,
                           "parallelism": f"dp{world}", "params_M": round(nparam / 1e6, 2),
@@ -239,7 +254,7 @@ def main():
                           "step_mfma_frac": round(value / world * fstep / 1e12 / PEAK_BF16_TFLOPS, 4),
                           "loss": loss_vals},
                "roofline": roof}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload == "cfg2":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
