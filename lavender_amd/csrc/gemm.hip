@@ -27,6 +27,9 @@ struct GemmArgs {
     int k_per_split;
     lav_gemm_epilogue e;
     uint32_t drop_thresh;
+    float* ws;            // split-K partial tiles [split][tile][128][128] fp32 (out_mode 2, splits > 1), or NULL
+    int ws_tiles;         // tiles per split in ws
+    int owner;            // out_mode 2 with one block per output tile: plain read-modify-write instead of atomics
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -256,6 +259,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             float* p = (float*)g.C + (long)grow * g.ldc + gcol;
             if (full) { *(float4*)p = *(float4*)&v[0]; *(float4*)(p + 4) = *(float4*)&v[4]; }
             else for (int x = 0; x < ncols; ++x) p[x] = v[x];
+        } else if (g.ws) {
+            // split-K partial: plain coalesced stores into this block's private workspace tile (tn_reduce_kernel sums
+            // the splits and does ONE read-modify-write of the gradient) -- fp32 atomics cost ~20 ps each on MI355X,
+            // a third of the weight-gradient GEMM time when every split flushes with them
+            float* p = g.ws + ((long)blockIdx.z * g.ws_tiles + (long)(m0 / ROWS) * ((g.N + BN - 1) / BN) + n0 / BN) * (ROWS * BN)
+                       + row * BN + cc * 8;
+            *(float4*)p = *(float4*)&v[0]; *(float4*)(p + 4) = *(float4*)&v[4];
+        } else if (g.owner) {
+            float* p = (float*)g.C + (long)grow * g.ldc + gcol;
+            if (full) {
+                float4 a = *(float4*)p, b = *(float4*)(p + 4);
+                a.x += v[0]; a.y += v[1]; a.z += v[2]; a.w += v[3]; b.x += v[4]; b.y += v[5]; b.z += v[6]; b.w += v[7];
+                *(float4*)p = a; *(float4*)(p + 4) = b;
+            } else for (int x = 0; x < ncols; ++x) p[x] += v[x];
         } else {
             float* p = (float*)g.C + (long)grow * g.ldc + gcol;
             for (int x = 0; x < ncols; ++x) atomicAdd(p + x, v[x]);
@@ -701,10 +718,66 @@ __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
     }
 }
 
+// ---- split-K reduction: C[r][c] += sum_s ws[s][tile(r,c)][r % 128][c % 128] -------------------------------------
+// 64 float4 outputs per block x 4 split lanes (each sums every 4th split, loads unrolled for memory parallelism),
+// merged through LDS; one plain read-modify-write of C per output.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, int tiles, int tiles_n, int M, int N,
+                                                       float* __restrict__ C, long ldc) {
+    __shared__ float4 part[4][64];
+    const int n4 = N >> 2;
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + o;
+    const bool valid = idx < (long)M * n4;
+    const int row = valid ? (int)(idx / n4) : 0, col = valid ? (int)(idx % n4) * 4 : 0;
+    const long off = ((long)(row / BM) * tiles_n + col / BN) * (BM * BN) + (row % BM) * BN + (col % BN);
+    const long stride = (long)tiles * (BM * BN);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+        int sp = sl;
+        for (; sp + 12 < splits; sp += 16) {
+            const float4 v0 = *(const float4*)(ws + (long)sp * stride + off);
+            const float4 v1 = *(const float4*)(ws + (long)(sp + 4) * stride + off);
+            const float4 v2 = *(const float4*)(ws + (long)(sp + 8) * stride + off);
+            const float4 v3 = *(const float4*)(ws + (long)(sp + 12) * stride + off);
+            a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+            a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; sp < splits; sp += 4) {
+            const float4 v = *(const float4*)(ws + (long)sp * stride + off);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    part[sl][o] = a;
+    __syncthreads();
+    if (sl == 0 && valid) {
+        const float4 b = part[1][o], c = part[2][o], d = part[3][o];
+        float4* p = (float4*)(C + (long)row * ldc + col);
+        float4 r = *p;
+        r.x += (a.x + b.x) + (c.x + d.x); r.y += (a.y + b.y) + (c.y + d.y);
+        r.z += (a.z + b.z) + (c.z + d.z); r.w += (a.w + b.w) + (c.w + d.w);
+        *p = r;
+    }
+}
+
+// process-wide split-K workspace (grown on demand).  Calls of lav_gemm_bf16 with splits > 1 must therefore be
+// stream-ordered with respect to each other (the product issues every GEMM on one stream).
+static float* g_splitk_ws = nullptr;
+static size_t g_splitk_ws_bytes = 0;
+static float* splitk_workspace(size_t bytes) {
+    if (bytes > g_splitk_ws_bytes) {
+        if (g_splitk_ws) { (void)hipDeviceSynchronize(); (void)hipFree(g_splitk_ws); g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; }
+        size_t want = bytes < ((size_t)64 << 20) ? ((size_t)64 << 20) : bytes + bytes / 2;
+        if (hipMalloc((void**)&g_splitk_ws, want) != hipSuccess) { (void)hipGetLastError(); g_splitk_ws = nullptr; return nullptr; }
+        g_splitk_ws_bytes = want;
+    }
+    return g_splitk_ws;
+}
+
 // test hook: route everything through the 128x128 kernel (set by LAV_GEMM_SMALL=1)
 static const bool lav_gemm_force_small = getenv("LAV_GEMM_SMALL") != nullptr;
 static const bool lav_gemm_no_huge = getenv("LAV_GEMM_NO_HUGE") != nullptr;
 static const bool lav_gemm_tn_big = getenv("LAV_GEMM_TN_BIG") != nullptr;
+static const bool lav_gemm_atomic_flush = getenv("LAV_GEMM_ATOMIC_FLUSH") != nullptr;   // test hook: the old atomic split-K flush
 
 extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B,
                              long ldb, void* C, long ldc, const lav_gemm_epilogue* epi, int splits) {
@@ -794,6 +867,23 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     }
     if (layout == 0) hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, block, GEMM_LDS_BYTES, s, g);
     else if (layout == 1) hipLaunchKernelGGL((gemm_kernel<true, false, 1>), grid, block, GEMM_LDS_BYTES, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<false, false, 2>), grid, dim3(NT_ * 2), 131072, s, g);
+    else {
+        // weight gradients (out_mode 2): one block per tile -> plain read-modify-write; split-K -> private partial tiles +
+        // one reduction pass.  Atomics only remain for the generic cases (ragged N, forced by LAV_GEMM_ATOMIC_FLUSH).
+        bool reduce = false;
+        if (g.e.out_mode == 2 && !lav_gemm_atomic_flush) {
+            if (splits == 1) g.owner = 1;
+            else if ((N % 4) == 0 && (ldc % 4) == 0) {
+                float* ws = splitk_workspace((size_t)splits * tiles * BM * BN * sizeof(float));
+                if (ws) { g.ws = ws; g.ws_tiles = tiles; reduce = true; }
+            }
+        }
+        hipLaunchKernelGGL((gemm_kernel<false, false, 2>), grid, dim3(NT_ * 2), 131072, s, g);
+        if (reduce) {
+            const long n = (long)M * (N / 4);
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, g.ws, splits, tiles,
+                               (N + BN - 1) / BN, M, N, (float*)C, ldc);
+        }
+    }
     return lav_check_launch("lav_gemm_bf16");
 }

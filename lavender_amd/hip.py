@@ -71,12 +71,13 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
 
 def splits_for(M, N, K, keep=False):
     """split-K factor for weight-gradient GEMMs.  Measured on MI355X (tools/tn_probe.py): the 8-wave 128x128 TN kernel
-    is fastest at about 190-260 blocks (<= one per CU); every extra split adds a full fp32-atomic output tile."""
+    (one resident block per CU) is fastest when tiles x splits lands just under 256 blocks; the partial tiles go
+    to a workspace and are summed by one reduction pass, so extra splits are cheap."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 200:
         return 1
-    s = 3 if 128 < tiles <= 160 else max(1, int(round(208.0 / tiles)))
-    return int(max(1, min(s, 128, (K + 255) // 256)))
+    s = 5 if tiles > 128 else max(1, 256 // tiles)
+    return int(max(1, min(s, 256, (K + 255) // 256)))
 
 
 def _gather(g):
