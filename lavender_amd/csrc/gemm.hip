@@ -138,21 +138,35 @@ __device__ __forceinline__ bf16x8 frag_read(const char* lds, int t16, int ks, in
 // ---- fused epilogue over the fp32 accumulator tile staged in LDS (row stride CSTRIDE): all NTHR threads, 8-wide
 // row chunks, 16-byte global accesses.  Order: alpha, bias, [preact], GELU, GELU', dropout, drop-path scale,
 // residual, [column sums], store.
-template <int ROWS, int NTHR>
+// F = compile-time feature mask: the large-tile kernels are instantiated for the handful of epilogue shapes the
+// training step uses, so that each runs straight-line code (the all-features version is ~600 basic blocks of
+// uniform branches and costs more than the k-loop on the short-K GEMMs of this model).
+enum : unsigned { EF_BIAS = 1, EF_ACT = 2, EF_GIN = 4, EF_DROP = 8, EF_RSCALE = 16, EF_RES = 32, EF_COLSUM = 64,
+                  EF_GENERIC = 0x8000, EF_ALL = 0xFFFF };
+
+template <int ROWS, int NTHR, unsigned F = EF_ALL>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int m0, int n0) {
     const lav_gemm_epilogue& e = g.e;
+    constexpr bool GEN = (F & EF_GENERIC) != 0;
+    const bool has_bias = (F & EF_BIAS) && e.bias;
+    const bool has_gelu = (F & EF_ACT) && e.act == 1;
+    const bool has_gin = (F & EF_GIN) && e.gelu_in;
+    const bool has_drop = (F & EF_DROP) && e.dropout_p > 0.f;
+    const bool has_rscale = (F & EF_RSCALE) && e.row_scale;
+    const bool has_res = (F & EF_RES) && e.residual;
+    const bool has_colsum = (F & EF_COLSUM) && e.colsum;
     const int etid = threadIdx.x;
     const int cc = etid & 15;
     const int gcol = n0 + cc * 8;
     float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int ncols = min(8, g.N - gcol);              // <=0: chunk outside
-    if (e.bias && ncols > 0) {
+    if (has_bias && ncols > 0) {
 #pragma unroll
         for (int x = 0; x < 8; ++x)
             if (x < ncols) bias[x] = e.bias[gcol + x];
     }
-    const bool full = ncols == 8;
+    const bool full = GEN ? ncols == 8 : true;     // specialised variants are only dispatched when N % 8 == 0
     constexpr int NIT = ROWS / (NTHR / 16);
     constexpr int GRP = 4;                                 // rows handled together: their gelu_in / residual loads are
     static_assert(NIT % GRP == 0, "epilogue row grouping");  // issued back-to-back so HBM latency is paid once per group
@@ -164,8 +178,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             const int grow = m0 + (etid >> 4) + (NTHR / 16) * (j0 + u);
             pre_g[u] = make_uint4(0, 0, 0, 0); pre_r[u] = pre_g[u];
             if (full && grow < g.M) {
-                if (e.gelu_in) pre_g[u] = *(const uint4*)((const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol);
-                if (e.residual) pre_r[u] = *(const uint4*)((const bf16_t*)e.residual + (long)grow * e.ldr + gcol);
+                if (has_gin) pre_g[u] = *(const uint4*)((const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol);
+                if (has_res) pre_r[u] = *(const uint4*)((const bf16_t*)e.residual + (long)grow * e.ldr + gcol);
             }
         }
 #pragma unroll
@@ -179,12 +193,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         *(float4*)&v[4] = *(const float4*)&cl[row * CSTRIDE + cc * 8 + 4];
 #pragma unroll
         for (int x = 0; x < 8; ++x) v[x] = v[x] * e.alpha + bias[x];
-        if (e.preact && !e.preact_is_grad) {
+        if (GEN && e.preact && !e.preact_is_grad) {
             bf16_t* p = (bf16_t*)e.preact + (long)grow * e.ldp + gcol;
             if (full) *(uint4*)p = pack8(v);
             else for (int x = 0; x < ncols; ++x) p[x] = f2bf(v[x]);
         }
-        if (e.act == 1) {
+        if (has_gelu) {
             if (e.preact && e.preact_is_grad) {
                 // GELU and GELU' share erf and exp: y = z Phi(z), y' = Phi(z) + z phi(z); y' is what the backward needs
                 float gp[8];
@@ -203,7 +217,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
                 for (int x = 0; x < 8; ++x) v[x] = gelu_f(v[x]);
             }
         }
-        if (e.act == 2) {                                  // ReLU (score head, main_pretrain_task_specific.py:131)
+        if (GEN && e.act == 2) {                                  // ReLU (score head, main_pretrain_task_specific.py:131)
             if (e.preact && e.preact_is_grad) {
                 float gp[8];
 #pragma unroll
@@ -215,12 +229,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
 #pragma unroll
             for (int x = 0; x < 8; ++x) v[x] = fmaxf(v[x], 0.f);
         }
-        if (e.gelu_in) {
+        if (has_gin) {
             const bf16_t* p = (const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol;
             float h[8];
             if (full) unpack8(pre_g[u], h);
             else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? bf2f(p[x]) : 0.f;
-            if (e.gelu_in_is_grad) {
+            if (!GEN || e.gelu_in_is_grad) {
 #pragma unroll
                 for (int x = 0; x < 8; ++x) v[x] *= h[x];
             } else {
@@ -228,18 +242,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
                 for (int x = 0; x < 8; ++x) v[x] *= gelu_grad_f(h[x]);
             }
         }
-        if (e.dropout_p > 0.f) {
+        if (has_drop) {
             const float inv = 1.0f / (1.0f - e.dropout_p);
 #pragma unroll
             for (int x = 0; x < 8; ++x)
                 v[x] = lav_keep(e.seed, (uint32_t)grow * (uint32_t)g.N + (uint32_t)(gcol + x), g.drop_thresh) ? v[x] * inv : 0.f;
         }
-        if (e.row_scale) {
+        if (has_rscale) {
             const float s = e.row_scale[grow / e.rows_per_group];
 #pragma unroll
             for (int x = 0; x < 8; ++x) v[x] *= s;
         }
-        if (e.residual) {
+        if (has_res) {
             const bf16_t* p = (const bf16_t*)e.residual + (long)grow * e.ldr + gcol;
             float h[8];
             if (full) unpack8(pre_r[u], h);
@@ -247,11 +261,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
 #pragma unroll
             for (int x = 0; x < 8; ++x) v[x] += h[x];
         }
-        if (e.colsum) {
+        if (has_colsum) {
 #pragma unroll
             for (int x = 0; x < 8; ++x) csum[x] += v[x];
         }
-        if (e.out_mode == 0) {
+        if (!GEN || e.out_mode == 0) {
             bf16_t* p = (bf16_t*)g.C + (long)grow * g.ldc + gcol;
             if (full) *(uint4*)p = pack8(v);
             else for (int x = 0; x < ncols; ++x) p[x] = f2bf(v[x]);
@@ -279,7 +293,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         }
       }
     }
-    if (e.colsum) {
+    if (has_colsum) {
         __syncthreads();
         float* red = cl;                                  // [NTHR/16][128]
 #pragma unroll
@@ -509,7 +523,7 @@ __device__ __forceinline__ bf16x8 huge_frag_strided(const char* lds, int t16, in
     return u.v;
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, unsigned F = EF_ALL>
 __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -606,7 +620,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
                 cl[row * CSTRIDE + col] = acc[i][j][r];
             }
     __syncthreads();
-    gemm_epilogue<BIG_BM, 512>(g, cl, m0, n0);
+    gemm_epilogue<BIG_BM, 512, F>(g, cl, m0, n0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -619,7 +633,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
 #define HUGE_STAGE 65536
 #define HUGE_LDS (BIG_BM * CSTRIDE * 4 > 2 * HUGE_STAGE ? BIG_BM * CSTRIDE * 4 : 2 * HUGE_STAGE)
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, unsigned F = EF_ALL>
 __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -713,7 +727,7 @@ __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
                     }
         }
         __syncthreads();
-        gemm_epilogue<BIG_BM, 512>(g, cl, m0, n0 + h * 128);
+        gemm_epilogue<BIG_BM, 512, F>(g, cl, m0, n0 + h * 128);
         __syncthreads();
     }
 }
@@ -816,12 +830,47 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     const bool big = layout != 2 && splits == 1 && (K % BKT) == 0 && M >= 2048 && !lav_gemm_force_small;
     static bool huge_attr = false;
     if (!huge_attr) {
-        hipFuncSetAttribute((const void*)gemm_huge_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HUGE_LDS);
-        hipFuncSetAttribute((const void*)gemm_huge_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, HUGE_LDS);
         hipFuncSetAttribute((const void*)gemm_huge_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, HUGE_LDS);
         (void)hipGetLastError();
         huge_attr = true;
     }
+    // epilogue feature mask of this call -> smallest instantiated superset (EF_ALL = the generic code)
+    unsigned fm = 0;
+    if (g.e.bias) fm |= EF_BIAS;
+    if (g.e.act == 1 && (!g.e.preact || g.e.preact_is_grad)) fm |= EF_ACT;
+    else if (g.e.act != 0 || g.e.preact) fm |= EF_GENERIC;
+    if (g.e.gelu_in) fm |= g.e.gelu_in_is_grad ? EF_GIN : EF_GENERIC;
+    if (g.e.dropout_p > 0.f) fm |= EF_DROP;
+    if (g.e.row_scale) fm |= EF_RSCALE;
+    if (g.e.residual) fm |= EF_RES;
+    if (g.e.colsum) fm |= EF_COLSUM;
+    if (g.e.out_mode != 0 || (N % 8) != 0) fm |= EF_GENERIC;
+    constexpr unsigned S_B = EF_BIAS, S_BG = EF_BIAS | EF_ACT, S_GC = EF_GIN | EF_RSCALE | EF_COLSUM,
+                       S_BDR = EF_BIAS | EF_DROP | EF_RSCALE | EF_RES;
+    const unsigned fsel = !(fm & ~S_B) ? S_B : !(fm & ~S_BG) ? S_BG : !(fm & ~S_GC) ? S_GC : !(fm & ~S_BDR) ? S_BDR : EF_ALL;
+#define LAV_LAUNCH_ONE(KERN, AKC_, BKC_, F_, GRID, LDS)                                                                   \
+    do {                                                                                                                  \
+        static bool attr_done = false;                                                                                    \
+        if (!attr_done) {                                                                                                 \
+            hipFuncSetAttribute((const void*)KERN<AKC_, BKC_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);      \
+            (void)hipGetLastError();                                                                                      \
+            attr_done = true;                                                                                             \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((KERN<AKC_, BKC_, F_>), GRID, dim3(512), LDS, s, g);                                           \
+    } while (0)
+#define LAV_LAUNCH_BY_LAYOUT(KERN, F_, GRID, LDS)                                                                         \
+    do {                                                                                                                  \
+        if (layout == 0) LAV_LAUNCH_ONE(KERN, true, true, F_, GRID, LDS);                                                 \
+        else LAV_LAUNCH_ONE(KERN, true, false, F_, GRID, LDS);                                                            \
+    } while (0)
+#define LAV_LAUNCH_BY_FEATURES(KERN, GRID, LDS)                                                                           \
+    do {                                                                                                                  \
+        if (fsel == S_B) LAV_LAUNCH_BY_LAYOUT(KERN, S_B, GRID, LDS);                                                      \
+        else if (fsel == S_BG) LAV_LAUNCH_BY_LAYOUT(KERN, S_BG, GRID, LDS);                                               \
+        else if (fsel == S_GC) LAV_LAUNCH_BY_LAYOUT(KERN, S_GC, GRID, LDS);                                               \
+        else if (fsel == S_BDR) LAV_LAUNCH_BY_LAYOUT(KERN, S_BDR, GRID, LDS);                                             \
+        else LAV_LAUNCH_BY_LAYOUT(KERN, EF_ALL, GRID, LDS);                                                               \
+    } while (0)
     // pick the tile by estimated machine fill: tiles / (rounds * resident slots), weighted by the tile's own efficiency
     auto fill = [](long tiles, long slots, double w) { return w * (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
     const long t_small = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -832,8 +881,7 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     if (big && !lav_gemm_no_huge && f_huge >= f_big && f_huge >= f_small) {
         g.k_per_split = K;
         dim3 hgrid((unsigned)t_huge);
-        if (layout == 0) hipLaunchKernelGGL((gemm_huge_kernel<true, true>), hgrid, dim3(512), HUGE_LDS, s, g);
-        else hipLaunchKernelGGL((gemm_huge_kernel<true, false>), hgrid, dim3(512), HUGE_LDS, s, g);
+        LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
         return lav_check_launch("lav_gemm_bf16");
     }
     // weight gradients on the 256x128 three-stage kernel: opt-in experiment (LAV_GEMM_TN_BIG=1).  Measured on MI355X it
@@ -852,17 +900,9 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         return lav_check_launch("lav_gemm_bf16");
     }
     if (big && f_big >= f_small) {
-        static bool big_attr = false;
-        if (!big_attr) {
-            hipFuncSetAttribute((const void*)gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
-            hipFuncSetAttribute((const void*)gemm_big_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
-            (void)hipGetLastError();
-            big_attr = true;
-        }
         dim3 bgrid(((M + BIG_BM - 1) / BIG_BM) * ((N + BN - 1) / BN));
         g.k_per_split = K;
-        if (layout == 0) hipLaunchKernelGGL((gemm_big_kernel<true, true>), bgrid, dim3(512), BIG_LDS, s, g);
-        else hipLaunchKernelGGL((gemm_big_kernel<true, false>), bgrid, dim3(512), BIG_LDS, s, g);
+        LAV_LAUNCH_BY_FEATURES(gemm_big_kernel, bgrid, BIG_LDS);
         return lav_check_launch("lav_gemm_bf16");
     }
     if (layout == 0) hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, block, GEMM_LDS_BYTES, s, g);
