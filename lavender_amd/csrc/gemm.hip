@@ -142,11 +142,41 @@ __device__ __forceinline__ bf16x8 frag_read(const char* lds, int t16, int ks, in
 // training step uses, so that each runs straight-line code (the all-features version is ~600 basic blocks of
 // uniform branches and costs more than the k-loop on the short-K GEMMs of this model).
 enum : unsigned { EF_BIAS = 1, EF_ACT = 2, EF_GIN = 4, EF_DROP = 8, EF_RSCALE = 16, EF_RES = 32, EF_COLSUM = 64,
-                  EF_GENERIC = 0x8000, EF_ALL = 0xFFFF };
+                  EF_TNFLUSH = 0x4000, EF_GENERIC = 0x8000, EF_ALL = 0xFFFF };
 
 template <int ROWS, int NTHR, unsigned F = EF_ALL>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int m0, int n0) {
     const lav_gemm_epilogue& e = g.e;
+    if constexpr (F == EF_TNFLUSH) {
+        // weight-gradient flush only: alpha * acc -> split-K workspace tile | owned read-modify-write | fp32 atomics
+        const int etid = threadIdx.x, cc = etid & 15, gcol = n0 + cc * 8;
+        const int ncols = min(8, g.N - gcol);
+        constexpr int NIT = ROWS / (NTHR / 16);
+        float* wsp = g.ws ? g.ws + ((long)blockIdx.z * g.ws_tiles + (long)(m0 / ROWS) * ((g.N + BN - 1) / BN) + n0 / BN) * (ROWS * BN) + cc * 8
+                          : nullptr;
+#pragma unroll 4
+        for (int j = 0; j < NIT; ++j) {
+            const int row = (etid >> 4) + (NTHR / 16) * j, grow = m0 + row;
+            if (grow >= g.M || ncols <= 0) continue;
+            float4 a = *(const float4*)&cl[row * CSTRIDE + cc * 8], b = *(const float4*)&cl[row * CSTRIDE + cc * 8 + 4];
+            a.x *= e.alpha; a.y *= e.alpha; a.z *= e.alpha; a.w *= e.alpha; b.x *= e.alpha; b.y *= e.alpha; b.z *= e.alpha; b.w *= e.alpha;
+            if (wsp) {
+                *(float4*)(wsp + row * BN) = a; *(float4*)(wsp + row * BN + 4) = b;
+            } else {
+                float* p = (float*)g.C + (long)grow * g.ldc + gcol;
+                if (g.owner && ncols == 8) {
+                    float4 c = *(float4*)p, d = *(float4*)(p + 4);
+                    c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w; d.x += b.x; d.y += b.y; d.z += b.z; d.w += b.w;
+                    *(float4*)p = c; *(float4*)(p + 4) = d;
+                } else {
+                    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    if (g.owner) { for (int x = 0; x < ncols; ++x) p[x] += v[x]; }
+                    else for (int x = 0; x < ncols; ++x) atomicAdd(p + x, v[x]);
+                }
+            }
+        }
+        return;
+    }
     constexpr bool GEN = (F & EF_GENERIC) != 0;
     const bool has_bias = (F & EF_BIAS) && e.bias;
     const bool has_gelu = (F & EF_ACT) && e.act == 1;
@@ -311,7 +341,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
 // KG = number of 4-wave groups per block.  KG == 2 (weight gradients): the two groups walk alternate k-tiles of
 // the SAME output tile with private LDS stages and merge their accumulators through LDS -- twice the waves per
 // CU without doubling the number of fp32-atomic output tiles (the epilogue atomics are what caps split-K).
-template <bool AK, bool BK, int KG>
+template <bool AK, bool BK, int KG, unsigned F = EF_ALL>
 __global__ __launch_bounds__(NT_ * KG) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const int grp = KG == 1 ? 0 : (threadIdx.x >> 8);
@@ -464,7 +494,7 @@ __global__ __launch_bounds__(NT_ * KG) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    gemm_epilogue<BM, NT_ * KG>(g, cl, m0, n0);
+    gemm_epilogue<BM, NT_ * KG, F>(g, cl, m0, n0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -509,6 +539,26 @@ __device__ __forceinline__ void huge_glds_strided(char* lds, const bf16_t* __res
         const bf16_t* src = P + (long)(k0 + krow) * ld + col;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lds + t * 1024), 16, 0, 0);
+    }
+}
+
+// drop-path row skipping for the large-tile weight-gradient kernels (A tile = [64 k][256 m], 512-byte k-rows):
+// returns 0 when every contraction row of the k-tile belongs to a dropped sample (skip the MFMAs), 1 when all rows are
+// kept, 2 when the tile straddles a kept and a dropped sample -- then the dropped k-rows are zeroed in LDS.
+__device__ __forceinline__ int tn_keep_mode(const lav_gemm_epilogue& e, int k0, int& kb, bool& keep0, bool& keep1) {
+    const int s0 = k0 / e.k_rows_per_group;
+    kb = (s0 + 1) * e.k_rows_per_group - k0;                 // rows [0, kb) of the tile belong to sample s0
+    keep0 = e.k_keep[s0] != 0.f;
+    keep1 = kb < BKT ? e.k_keep[s0 + 1] != 0.f : keep0;
+    return (keep0 && keep1) ? 1 : (!keep0 && !keep1) ? 0 : 2;
+}
+
+__device__ __forceinline__ void tn_zero_a_rows(char* lds_a, int kb, bool keep0, bool keep1, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int krow = p * 16 + (tid >> 5);
+        const bool keep = krow < kb ? keep0 : keep1;
+        if (!keep) *(uint4*)(lds_a + krow * 512 + (tid & 31) * 16) = make_uint4(0, 0, 0, 0);
     }
 }
 
@@ -576,8 +626,18 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
         const char* lb = la + 32768;
         const bool more = kt + 2 < nk;
         if (more) issue(kt + 2);
+        int kmode = 1;
+        if (!AKC && g.e.k_keep) {
+            int kb; bool keep0, keep1;
+            kmode = tn_keep_mode(g.e, kbeg + kt * BKT, kb, keep0, keep1);
+            if (kmode == 2) {
+                tn_zero_a_rows(const_cast<char*>(la), kb, keep0, keep1, tid);
+                __syncthreads();
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (kmode == 0) break;
             bf16x8 fa[4], fb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i] = AKC ? frag_read<true>(la, wm * 4 + i, ks, lane) : huge_frag_strided(la, wm * 4 + i, ks, lane);
@@ -681,8 +741,18 @@ __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
         const char* la = smem + (kt & 1) * HUGE_STAGE;
         const char* lb = la + 32768;
         if (kt + 1 < nk) issue(kt + 1);
+        int kmode = 1;
+        if (!AKC && g.e.k_keep) {
+            int kb; bool keep0, keep1;
+            kmode = tn_keep_mode(g.e, kbeg + kt * BKT, kb, keep0, keep1);
+            if (kmode == 2) {
+                tn_zero_a_rows(const_cast<char*>(la), kb, keep0, keep1, tid);
+                __syncthreads();
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (kmode == 0) break;
             bf16x8 fa[8], fb[4];
 #pragma unroll
             for (int i = 0; i < 8; ++i) fa[i] = AKC ? frag_read<true>(la, wm * 8 + i, ks, lane) : huge_frag_strided(la, wm * 8 + i, ks, lane);
@@ -735,16 +805,16 @@ __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
 // ---- split-K reduction: C[r][c] += sum_s ws[s][tile(r,c)][r % 128][c % 128] -------------------------------------
 // 64 float4 outputs per block x 4 split lanes (each sums every 4th split, loads unrolled for memory parallelism),
 // merged through LDS; one plain read-modify-write of C per output.
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, int tiles, int tiles_n, int M, int N,
-                                                       float* __restrict__ C, long ldc) {
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, int tiles, int tiles_n, int rpt, int M,
+                                                       int N, float* __restrict__ C, long ldc) {
     __shared__ float4 part[4][64];
     const int n4 = N >> 2;
     const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long idx = (long)blockIdx.x * 64 + o;
     const bool valid = idx < (long)M * n4;
     const int row = valid ? (int)(idx / n4) : 0, col = valid ? (int)(idx % n4) * 4 : 0;
-    const long off = ((long)(row / BM) * tiles_n + col / BN) * (BM * BN) + (row % BM) * BN + (col % BN);
-    const long stride = (long)tiles * (BM * BN);
+    const long off = ((long)(row / rpt) * tiles_n + col / BN) * (rpt * BN) + (row % rpt) * BN + (col % BN);   // rpt rows per tile
+    const long stride = (long)tiles * (rpt * BN);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) {
         int sp = sl;
@@ -790,7 +860,7 @@ static float* splitk_workspace(size_t bytes) {
 // test hook: route everything through the 128x128 kernel (set by LAV_GEMM_SMALL=1)
 static const bool lav_gemm_force_small = getenv("LAV_GEMM_SMALL") != nullptr;
 static const bool lav_gemm_no_huge = getenv("LAV_GEMM_NO_HUGE") != nullptr;
-static const bool lav_gemm_tn_big = getenv("LAV_GEMM_TN_BIG") != nullptr;
+static const int lav_gemm_tn_kind = getenv("LAV_GEMM_TN_KIND") ? atoi(getenv("LAV_GEMM_TN_KIND")) : -1;   // probe hook: 0 = 128x128 only, 1 = at most 256x128, default = largest tile that fits
 static const bool lav_gemm_atomic_flush = getenv("LAV_GEMM_ATOMIC_FLUSH") != nullptr;   // test hook: the old atomic split-K flush
 
 extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B,
@@ -828,12 +898,6 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         attr_set = true;
     }
     const bool big = layout != 2 && splits == 1 && (K % BKT) == 0 && M >= 2048 && !lav_gemm_force_small;
-    static bool huge_attr = false;
-    if (!huge_attr) {
-        hipFuncSetAttribute((const void*)gemm_huge_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, HUGE_LDS);
-        (void)hipGetLastError();
-        huge_attr = true;
-    }
     // epilogue feature mask of this call -> smallest instantiated superset (EF_ALL = the generic code)
     unsigned fm = 0;
     if (g.e.bias) fm |= EF_BIAS;
@@ -884,21 +948,6 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
         return lav_check_launch("lav_gemm_bf16");
     }
-    // weight gradients on the 256x128 three-stage kernel: opt-in experiment (LAV_GEMM_TN_BIG=1).  Measured on MI355X it
-    // ties the 8-wave 128x128 split-K kernel per call and loses in the full step (167 vs 161 ms): with so few output
-    // tiles the machine fill (tiles x splits vs 256 CUs) decides, and the smaller tile quantises better.
-    if (layout == 2 && M >= 256 && (K % BKT) == 0 && (kps % BKT) == 0 && !g.e.k_keep && g.e.out_mode == 2 &&
-        !lav_gemm_force_small && lav_gemm_tn_big) {
-        static bool tn_attr = false;
-        if (!tn_attr) {
-            hipFuncSetAttribute((const void*)gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
-            (void)hipGetLastError();
-            tn_attr = true;
-        }
-        dim3 tgrid(((M + BIG_BM - 1) / BIG_BM) * ((N + BN - 1) / BN), 1, splits);
-        hipLaunchKernelGGL((gemm_big_kernel<false, false>), tgrid, dim3(512), BIG_LDS, s, g);
-        return lav_check_launch("lav_gemm_bf16");
-    }
     if (big && f_big >= f_small) {
         dim3 bgrid(((M + BIG_BM - 1) / BIG_BM) * ((N + BN - 1) / BN));
         g.k_per_split = K;
@@ -908,21 +957,44 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     if (layout == 0) hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, block, GEMM_LDS_BYTES, s, g);
     else if (layout == 1) hipLaunchKernelGGL((gemm_kernel<true, false, 1>), grid, block, GEMM_LDS_BYTES, s, g);
     else {
-        // weight gradients (out_mode 2): one block per tile -> plain read-modify-write; split-K -> private partial tiles +
-        // one reduction pass.  Atomics only remain for the generic cases (ragged N, forced by LAV_GEMM_ATOMIC_FLUSH).
+        // ---- weight gradients -------------------------------------------------------------------------------------
+        // flush (out_mode 2): one block per output tile -> plain read-modify-write; split-K -> private partial tiles in a
+        // workspace + one reduction pass.  fp32 atomics only remain for ragged N or LAV_GEMM_ATOMIC_FLUSH=1.
+        const bool plain = g.e.out_mode == 2 && !g.e.bias && !g.e.act && !g.e.preact && !g.e.gelu_in && g.e.dropout_p <= 0.f &&
+                           !g.e.row_scale && !g.e.residual && !g.e.colsum;
+        int kind = 0;                                        // 0: 128x128 two-group kernel, 1: 256x128, 2: 256x256
+        const bool large_ok = plain && (K % BKT) == 0 && (kps % BKT) == 0 && M >= 256 && !lav_gemm_force_small &&
+                              (!g.e.k_keep || g.e.k_rows_per_group >= BKT);
+        if (large_ok && lav_gemm_tn_kind != 0) kind = (N % 256) == 0 && lav_gemm_tn_kind != 1 ? 2 : 1;
+        const int rpt = kind ? BIG_BM : BM;
+        const int ws_tiles = ((M + rpt - 1) / rpt) * ((N + BN - 1) / BN);
         bool reduce = false;
         if (g.e.out_mode == 2 && !lav_gemm_atomic_flush) {
             if (splits == 1) g.owner = 1;
             else if ((N % 4) == 0 && (ldc % 4) == 0) {
-                float* ws = splitk_workspace((size_t)splits * tiles * BM * BN * sizeof(float));
-                if (ws) { g.ws = ws; g.ws_tiles = tiles; reduce = true; }
+                float* ws = splitk_workspace((size_t)splits * ws_tiles * rpt * BN * sizeof(float));
+                if (ws) { g.ws = ws; g.ws_tiles = ws_tiles; reduce = true; }
             }
         }
-        hipLaunchKernelGGL((gemm_kernel<false, false, 2>), grid, dim3(NT_ * 2), 131072, s, g);
+        if (kind == 2) {
+            static bool a2 = false;
+            if (!a2) { hipFuncSetAttribute((const void*)gemm_huge_kernel<false, false, EF_TNFLUSH>, hipFuncAttributeMaxDynamicSharedMemorySize, HUGE_LDS); (void)hipGetLastError(); a2 = true; }
+            hipLaunchKernelGGL((gemm_huge_kernel<false, false, EF_TNFLUSH>), dim3(((M + BIG_BM - 1) / BIG_BM) * (N / 256), 1, splits), dim3(512), HUGE_LDS, s, g);
+        } else if (kind == 1) {
+            static bool a1 = false;
+            if (!a1) { hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, EF_TNFLUSH>, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS); (void)hipGetLastError(); a1 = true; }
+            hipLaunchKernelGGL((gemm_big_kernel<false, false, EF_TNFLUSH>), dim3(ws_tiles, 1, splits), dim3(512), BIG_LDS, s, g);
+        } else if (plain) {
+            static bool a0 = false;
+            if (!a0) { hipFuncSetAttribute((const void*)gemm_kernel<false, false, 2, EF_TNFLUSH>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); (void)hipGetLastError(); a0 = true; }
+            hipLaunchKernelGGL((gemm_kernel<false, false, 2, EF_TNFLUSH>), grid, dim3(NT_ * 2), 131072, s, g);
+        } else {
+            hipLaunchKernelGGL((gemm_kernel<false, false, 2>), grid, dim3(NT_ * 2), 131072, s, g);
+        }
         if (reduce) {
             const long n = (long)M * (N / 4);
-            hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, g.ws, splits, tiles,
-                               (N + BN - 1) / BN, M, N, (float*)C, ldc);
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, g.ws, splits, ws_tiles,
+                               (N + BN - 1) / BN, rpt, M, N, (float*)C, ldc);
         }
     }
     return lav_check_launch("lav_gemm_bf16");

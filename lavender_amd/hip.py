@@ -70,9 +70,13 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
 
 
 def splits_for(M, N, K, keep=False):
-    """split-K factor for weight-gradient GEMMs.  Measured on MI355X (tools/tn_probe.py): the 8-wave 128x128 TN kernel
-    (one resident block per CU) is fastest when tiles x splits lands just under 256 blocks; the partial tiles go
-    to a workspace and are summed by one reduction pass, so extra splits are cheap."""
+    """split-K factor for weight-gradient GEMMs, matched to the kernel lav_gemm_bf16 picks for the shape (256x256 tiles
+    when M >= 256, N % 256 == 0 and K % 64 == 0; 256x128 when only N % 256 fails; else 128x128).  Measured on MI355X
+    (tools/tn_probe.py): every variant holds one block per CU and is fastest when tiles x splits lands just under 256;
+    partial tiles go to a workspace and are summed by one reduction pass, so extra splits are cheap."""
+    if M >= 256 and K % 64 == 0:
+        tiles = ((M + 255) // 256) * (N // 256 if N % 256 == 0 else (N + 127) // 128)
+        return int(max(1, min(256 // tiles if tiles <= 256 else 1, K // 256)))
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 200:
         return 1

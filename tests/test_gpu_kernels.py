@@ -103,6 +103,27 @@ def test_gemm_tn_splitk_rowsum_keep():
     close(dW, 2 * ref, atol=0.6, rtol=1e-2, what="accumulation across calls")
 
 
+@pytest.mark.parametrize("shape", [(512, 512, 3008), (304, 384, 3008), (768, 256, 6016)])
+@pytest.mark.parametrize("splits", [1, 3, 11])
+def test_gemm_tn_large_tiles_keep_rowsum(shape, splits):
+    """Weight-gradient GEMM on the 256x256 / 256x128 tile kernels (M >= 256, K % 64 == 0): split-K through the
+    workspace + reduction pass, drop-path row skipping with k-tiles that straddle kept / dropped samples (rows per
+    sample = 1000, not a multiple of the 64-row k-tile), fused bias gradient, accumulation across calls."""
+    M, N, Kd = shape
+    dY, X = rb(Kd, M), rb(Kd, N, seed=1)
+    ng = (Kd + 999) // 1000
+    keep = torch.tensor([1.25, 0.0, 1.25, 0.0, 0.0, 1.25, 1.25][:ng], device="cuda")
+    dW = torch.zeros(M, N, device="cuda")
+    db = torch.zeros(M, device="cuda")
+    K().gemm(2, dY, X, M, N, Kd, out=dW, accumulate=True, splits=splits, k_keep=keep, k_rows_per_group=1000, alpha=1.25, rowsum_a=db)
+    m = (keep != 0).float().repeat_interleave(1000)[:Kd, None].cpu()
+    ref = 1.25 * (dY.float().cpu() * m).t() @ X.float().cpu()
+    close(dW, ref, atol=0.3, rtol=1e-2, what="dW large tile + keep")
+    close(db, 1.25 * (dY.float().cpu() * m).sum(0), atol=0.3, rtol=1e-2, what="fused bias gradient")
+    K().gemm(2, dY, X, M, N, Kd, out=dW, accumulate=True, splits=splits)
+    close(dW, ref + dY.float().cpu().t() @ X.float().cpu(), atol=0.6, rtol=1e-2, what="accumulation, no keep")
+
+
 def test_gemm_ragged_vocab_tail():
     M, V, Kd = 64, 1018, 128                         # V % 8 == 2 like 30522
     ld = (V + 7) // 8 * 8
