@@ -295,7 +295,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
 #pragma unroll
             for (int x = 0; x < 8; ++x) csum[x] += v[x];
         }
-        if (!GEN || e.out_mode == 0) {
+        if (GEN && g.ws) {
+            // split-K partial: plain coalesced stores into this block's private workspace tile (a reduction pass sums the
+            // splits) -- fp32 atomics cost ~20 ps each on MI355X, a third of the GEMM time when every split flushes with them
+            float* p = g.ws + ((long)blockIdx.z * g.ws_tiles + (long)(m0 / ROWS) * ((g.N + BN - 1) / BN) + n0 / BN) * (ROWS * BN)
+                       + row * BN + cc * 8;
+            *(float4*)p = *(float4*)&v[0]; *(float4*)(p + 4) = *(float4*)&v[4];
+        } else if (!GEN || e.out_mode == 0) {
             bf16_t* p = (bf16_t*)g.C + (long)grow * g.ldc + gcol;
             if (full) *(uint4*)p = pack8(v);
             else for (int x = 0; x < ncols; ++x) p[x] = f2bf(v[x]);
@@ -303,13 +309,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             float* p = (float*)g.C + (long)grow * g.ldc + gcol;
             if (full) { *(float4*)p = *(float4*)&v[0]; *(float4*)(p + 4) = *(float4*)&v[4]; }
             else for (int x = 0; x < ncols; ++x) p[x] = v[x];
-        } else if (g.ws) {
-            // split-K partial: plain coalesced stores into this block's private workspace tile (tn_reduce_kernel sums
-            // the splits and does ONE read-modify-write of the gradient) -- fp32 atomics cost ~20 ps each on MI355X,
-            // a third of the weight-gradient GEMM time when every split flushes with them
-            float* p = g.ws + ((long)blockIdx.z * g.ws_tiles + (long)(m0 / ROWS) * ((g.N + BN - 1) / BN) + n0 / BN) * (ROWS * BN)
-                       + row * BN + cc * 8;
-            *(float4*)p = *(float4*)&v[0]; *(float4*)(p + 4) = *(float4*)&v[4];
         } else if (g.owner) {
             float* p = (float*)g.C + (long)grow * g.ldc + gcol;
             if (full) {
@@ -843,6 +842,23 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
+// split-K of a forward / input-gradient GEMM (bf16 output, no epilogue): C = bf16(sum_s ws[s]); 8 columns per thread
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ ws, int splits, int tiles, int tiles_n, int M, int N,
+                                                                bf16_t* __restrict__ C, long ldc) {
+    const int n8 = N >> 3;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * n8) return;
+    const int row = (int)(idx / n8), col = (int)(idx % n8) * 8;
+    const long off = ((long)(row / BM) * tiles_n + col / BN) * (BM * BN) + (row % BM) * BN + (col % BN);
+    const long stride = (long)tiles * (BM * BN);
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int sp = 0; sp < splits; ++sp) {
+        const float4 a = *(const float4*)(ws + (long)sp * stride + off), b = *(const float4*)(ws + (long)sp * stride + off + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    *(uint4*)(C + (long)row * ldc + col) = pack8(v);
+}
+
 // process-wide split-K workspace (grown on demand).  Calls of lav_gemm_bf16 with splits > 1 must therefore be
 // stream-ordered with respect to each other (the product issues every GEMM on one stream).
 static float* g_splitk_ws = nullptr;
@@ -879,7 +895,10 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     if (g.e.alpha == 0.f) g.e.alpha = 1.f;
     if (splits < 1) splits = 1;
     LAV_REQUIRE(!g.e.rowsum_a || layout == 2, "lav_gemm_bf16: rowsum_a is only defined for layout 2 (TN)");
-    LAV_REQUIRE(splits == 1 || g.e.out_mode == 2, "lav_gemm_bf16: split-K needs out_mode=2 (fp32 atomic accumulate)");
+    const bool no_epilogue = !g.e.bias && !g.e.act && !g.e.preact && !g.e.gelu_in && g.e.dropout_p <= 0.f && !g.e.row_scale &&
+                             !g.e.residual && !g.e.colsum && !g.e.rowsum_a && g.e.alpha == 1.f;
+    LAV_REQUIRE(splits == 1 || g.e.out_mode == 2 || (g.e.out_mode == 0 && layout != 2 && no_epilogue && (N % 8) == 0),
+                "lav_gemm_bf16: split-K needs out_mode=2 (fp32 accumulate), or a bf16 output without epilogue and N %% 8 == 0");
     LAV_REQUIRE(g.e.out_mode != 0 || (ldc % 8) == 0, "lav_gemm_bf16: bf16 output needs ldc %% 8 == 0");
     LAV_REQUIRE(g.e.out_mode == 0 || (ldc % 4) == 0, "lav_gemm_bf16: fp32 output needs ldc %% 4 == 0");
     int kps = ((K + splits - 1) / splits + BKT - 1) / BKT * BKT;
@@ -954,9 +973,21 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         LAV_LAUNCH_BY_FEATURES(gemm_big_kernel, bgrid, BIG_LDS);
         return lav_check_launch("lav_gemm_bf16");
     }
-    if (layout == 0) hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, block, GEMM_LDS_BYTES, s, g);
-    else if (layout == 1) hipLaunchKernelGGL((gemm_kernel<true, false, 1>), grid, block, GEMM_LDS_BYTES, s, g);
-    else {
+    if (layout != 2) {
+        const bool sk = splits > 1 && g.e.out_mode == 0;     // under-filled long-K problem (vocabulary contraction): workspace split-K
+        if (sk) {
+            g.ws = splitk_workspace((size_t)splits * tiles * BM * BN * sizeof(float));
+            LAV_REQUIRE(g.ws, "lav_gemm_bf16: split-K workspace allocation failed");
+            g.ws_tiles = tiles;
+        }
+        if (layout == 0) hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, block, GEMM_LDS_BYTES, s, g);
+        else hipLaunchKernelGGL((gemm_kernel<true, false, 1>), grid, block, GEMM_LDS_BYTES, s, g);
+        if (sk) {
+            const long n = (long)M * (N / 8);
+            hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g.ws, splits, tiles,
+                               (N + BN - 1) / BN, M, N, (bf16_t*)C, ldc);
+        }
+    } else {
         // ---- weight gradients -------------------------------------------------------------------------------------
         // flush (out_mode 2): one block per output tile -> plain read-modify-write; split-K -> private partial tiles in a
         // workspace + one reduction pass.  fp32 atomics only remain for ragged N or LAV_GEMM_ATOMIC_FLUSH=1.

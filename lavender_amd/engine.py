@@ -405,7 +405,7 @@ class MLMHeadFn(torch.autograd.Function):
             pad[:, :V].copy_(d2)
             d2 = pad[:, :V]
         K.gemm(2, d2, tn, V, Hd, R, out=G(dec.weight), accumulate=True, splits=K.splits_for(V, Hd, R), rowsum_a=G(dec.bias))
-        d_tn = K.gemm(1, d2, W16(dec.weight), R, Hd, V)
+        d_tn = K.gemm(1, d2, W16(dec.weight), R, Hd, V, splits=K.splits_nn(R, Hd, V))
         d_t = K.layernorm_bwd(d_tn, t, R, Hd, tr.LayerNorm.weight.data, mean, rstd, G(tr.LayerNorm.weight), G(tr.LayerNorm.bias))
         d_tpre = torch.empty((R, Hd), dtype=bf16, device=d_t.device)
         K.scale_mask_rows(d_t, R, Hd, out=d_tpre, colsum=G(tr.dense.bias), gelu_in=t_pre)

@@ -84,6 +84,15 @@ def splits_for(M, N, K, keep=False):
     return int(max(1, min(s, 256, (K + 255) // 256)))
 
 
+def splits_nn(M, N, K):
+    """split-K factor for a forward / input-gradient GEMM whose output is too small to fill the chip while K is long
+    (d_hidden = dlogits . W_dec: K = vocabulary).  128x128 tiles, two resident blocks per CU."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 256 or K < 4096 or N % 8:
+        return 1
+    return int(max(1, min(512 // tiles, K // 1024)))
+
+
 def _gather(g):
     if g is None:
         return None

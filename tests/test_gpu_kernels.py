@@ -124,6 +124,22 @@ def test_gemm_tn_large_tiles_keep_rowsum(shape, splits):
     close(dW, ref + dY.float().cpu().t() @ X.float().cpu(), atol=0.6, rtol=1e-2, what="accumulation, no keep")
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+def test_gemm_splitk_bf16_output(layout):
+    """Workspace split-K of a forward / input-gradient GEMM with a long ragged contraction (K = 30522-like vocabulary)."""
+    M, N, Kd = 200, 136, 5002
+    ldk = (Kd + 7) // 8 * 8
+    A = torch.zeros(M, ldk, device="cuda", dtype=torch.bfloat16)
+    A[:, :Kd] = rb(M, Kd, scale=0.1)
+    Bm = rb(N, ldk, seed=1, scale=0.1) if layout == 0 else rb(Kd, N, seed=1, scale=0.1)
+    if layout == 0:
+        Bm[:, Kd:] = 0
+    out = K().gemm(layout, A[:, :Kd], Bm[:, :Kd] if layout == 0 else Bm, M, N, Kd, splits=4)
+    ref = A[:, :Kd].float() @ (Bm[:, :Kd].float().t() if layout == 0 else Bm.float())
+    close(out, ref, atol=2e-2, rtol=1e-2, what="split-K bf16 output")
+    assert K().splits_nn(1024, 768, 30522) > 1 and K().splits_nn(36096, 768, 3072) == 1
+
+
 def test_gemm_ragged_vocab_tail():
     M, V, Kd = 64, 1018, 128                         # V % 8 == 2 like 30522
     ld = (V + 7) // 8 * 8
