@@ -212,7 +212,12 @@ def main():
         e0.record()
         r = orig(layout, A, Bm, M, N, Kd, **kw)
         e1.record()
-        rec.append((layout, 2.0 * M * N * Kd, e0, e1))
+        # algorithmic HBM bytes of the launch: operands once, output once, plus the epilogue tensors it reads / writes
+        by = 2.0 * (M * Kd + N * Kd + M * N)
+        for k in ("preact", "gelu_in", "residual"):
+            if kw.get(k) is not None:
+                by += 2.0 * M * N
+        rec.append((layout, 2.0 * M * N * Kd, e0, e1, by))
         return r
     if rank == 0:
         K.gemm = timed
@@ -221,14 +226,25 @@ def main():
     K.gemm = orig
     if rank == 0:
         by = {}
-        for layout, fl, e0, e1 in rec:
-            d = by.setdefault(layout, [0, 0.0, 0.0])
-            d[0] += 1; d[1] += fl; d[2] += e0.elapsed_time(e1) * 1e-3
-        n, fl, tm = by[0]
+        for layout, fl, e0, e1, nbytes in rec:
+            d = by.setdefault(layout, [0, 0.0, 0.0, 0.0])
+            d[0] += 1; d[1] += fl; d[2] += e0.elapsed_time(e1) * 1e-3; d[3] += nbytes
+        n, fl, tm, nb = by[0]
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
+                pm = json.load(fh)
+            if a.workload == "cfg2" and B == 32 and a.layers == 12 and a.size == "base":
+                traffic = pm["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         tot_fl = sum(v[1] for v in by.values()); tot_t = sum(v[2] for v in by.values())
         roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T GEMMs: gemm_huge/big/gemm_kernel<NT>)",
                 "achieved": round(fl / tm / 1e12, 2),
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tm / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tm / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.md)",
+                "algorithmic_bytes_per_launch": round(nb / n),
                 "launches_per_step": n, "avg_launch_us": round(tm / n * 1e6, 2), "avg_launch_gflop": round(fl / n / 1e9, 3),
                 "all_gemm_layouts": {"launches": sum(v[0] for v in by.values()), "tflops": round(tot_fl / tot_t / 1e12, 2),
                                      "gemm_time_ms_per_step": round(tot_t * 1e3, 2)}}
