@@ -528,10 +528,11 @@ __device__ __forceinline__ void big_glds(char* lds, const bf16_t* __restrict__ P
     }
 }
 
+template <int IPW = 4>
 __device__ __forceinline__ void huge_glds_strided(char* lds, const bf16_t* __restrict__ P, long ld, int o0, int O, int k0, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                          // [64 k][256 n] bf16, 512-byte rows, 2 rows per wave-instruction
-        const int t = wave * 4 + i;
+    for (int i = 0; i < IPW; ++i) {                        // [64 k][256 n] bf16, 512-byte rows, 2 rows per wave-instruction
+        const int t = wave * IPW + i;
         const int krow = t * 2 + (lane >> 5);
         const int ch = ((lane & 31) >> 1) ^ skey(krow);
         const int col = min(o0 + ch * 16 + (lane & 1) * 8, ((O + 7) & ~7) - 8);
@@ -552,10 +553,11 @@ __device__ __forceinline__ int tn_keep_mode(const lav_gemm_epilogue& e, int k0, 
     return (keep0 && keep1) ? 1 : (!keep0 && !keep1) ? 0 : 2;
 }
 
+template <int NTHR = 512>
 __device__ __forceinline__ void tn_zero_a_rows(char* lds_a, int kb, bool keep0, bool keep1, int tid) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int krow = p * 16 + (tid >> 5);
+    for (int p = 0; p < 2048 / NTHR; ++p) {
+        const int krow = p * (NTHR / 32) + (tid >> 5);
         const bool keep = krow < kb ? keep0 : keep1;
         if (!keep) *(uint4*)(lds_a + krow * 512 + (tid & 31) * 16) = make_uint4(0, 0, 0, 0);
     }
@@ -692,11 +694,18 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
 #define HUGE_STAGE 65536
 #define HUGE_LDS (BIG_BM * CSTRIDE * 4 > 2 * HUGE_STAGE ? BIG_BM * CSTRIDE * 4 : 2 * HUGE_STAGE)
 
-template <bool AKC, bool BKC, unsigned F = EF_ALL>
-__global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
+// NW = waves per block.  8: 2 x 4 waves of 128x64 (shipped).  Per k-tile the LDS pipe moves 192 KB of fragment reads +
+// 64 KB of direct-to-LDS writes = 2048 clk, exactly the MFMA time -- the k-loop sits near 47 % of the MFMA peak.
+// NW = 4 (2 x 2 waves of 128x128, 256 accumulator registers, one wave per SIMD, 128 KB of reads) was measured at HALF
+// the rate: with a single wave per SIMD nothing covers the LDS latency between the compiler's read/MFMA groups.
+template <bool AKC, bool BKC, unsigned F, int NW>
+__device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
+    constexpr int WN = NW / 2;                            // wave grid 2 (m) x WN (n)
+    constexpr int NJ = 16 / WN;                           // 16-column fragments per wave
+    constexpr int IPW = 32 / NW;                          // direct-to-LDS wave-instructions per operand tile per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = g.N / 256, tiles_m = (g.M + BIG_BM - 1) / BIG_BM;
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
@@ -709,11 +718,11 @@ __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nk = (kend - kbeg) / BKT;
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][NJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // TN: bias gradient (row sums of A^T) on the matrix cores against a ones fragment, wn == 0 waves of the n0 == 0 blocks
     const bool do_rowsum = !AKC && g.e.rowsum_a != nullptr && n0 == 0 && wn == 0;
     f32x4 acc1[8];
@@ -727,10 +736,10 @@ __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
     auto issue = [&](int kt) {
         char* st = smem + (kt & 1) * HUGE_STAGE;
         const int k0 = kbeg + kt * BKT;
-        if (AKC) big_glds<true, 4>(st, g.A, g.lda, m0, g.M, k0, wave, lane);
-        else huge_glds_strided(st, g.A, g.lda, m0, g.M, k0, wave, lane);
-        if (BKC) big_glds<true, 4>(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);
-        else huge_glds_strided(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);
+        if (AKC) big_glds<true, IPW>(st, g.A, g.lda, m0, g.M, k0, wave, lane);
+        else huge_glds_strided<IPW>(st, g.A, g.lda, m0, g.M, k0, wave, lane);
+        if (BKC) big_glds<true, IPW>(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);
+        else huge_glds_strided<IPW>(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);
     };
     if (nk > 0) issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -745,22 +754,22 @@ __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
             int kb; bool keep0, keep1;
             kmode = tn_keep_mode(g.e, kbeg + kt * BKT, kb, keep0, keep1);
             if (kmode == 2) {
-                tn_zero_a_rows(const_cast<char*>(la), kb, keep0, keep1, tid);
+                tn_zero_a_rows<NW * 64>(const_cast<char*>(la), kb, keep0, keep1, tid);
                 __syncthreads();
             }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (kmode == 0) break;
-            bf16x8 fa[8], fb[4];
+            bf16x8 fa[8], fb[NJ];
 #pragma unroll
             for (int i = 0; i < 8; ++i) fa[i] = AKC ? frag_read<true>(la, wm * 8 + i, ks, lane) : huge_frag_strided(la, wm * 8 + i, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = BKC ? frag_read<true>(lb, wn * 4 + j, ks, lane) : huge_frag_strided(lb, wn * 4 + j, ks, lane);
+            for (int j = 0; j < NJ; ++j) fb[j] = BKC ? frag_read<true>(lb, wn * NJ + j, ks, lane) : huge_frag_strided(lb, wn * NJ + j, ks, lane);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             if (!AKC && do_rowsum) {
 #pragma unroll
@@ -783,23 +792,26 @@ __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) {
     float* cl = (float*)smem;
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
-        if ((wn >> 1) == h) {
+        if (wn / (WN / 2) == h) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         int row = wm * 128 + i * 16 + (lane >> 4) * 4 + r;
-                        int col = (wn & 1) * 64 + j * 16 + (lane & 15);
+                        int col = (wn % (WN / 2)) * (NJ * 16) + j * 16 + (lane & 15);
                         cl[row * CSTRIDE + col] = acc[i][j][r];
                     }
         }
         __syncthreads();
-        gemm_epilogue<BIG_BM, 512, F>(g, cl, m0, n0 + h * 128);
+        gemm_epilogue<BIG_BM, NW * 64, F>(g, cl, m0, n0 + h * 128);
         __syncthreads();
     }
 }
+
+template <bool AKC, bool BKC, unsigned F = EF_ALL>
+__global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 8>(g); }
 
 // ---- split-K reduction: C[r][c] += sum_s ws[s][tile(r,c)][r % 128][c % 128] -------------------------------------
 // 64 float4 outputs per block x 4 split lanes (each sums every 4th split, loads unrolled for memory parallelism),
@@ -931,6 +943,8 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     constexpr unsigned S_B = EF_BIAS, S_BG = EF_BIAS | EF_ACT, S_GC = EF_GIN | EF_RSCALE | EF_COLSUM,
                        S_BDR = EF_BIAS | EF_DROP | EF_RSCALE | EF_RES;
     const unsigned fsel = !(fm & ~S_B) ? S_B : !(fm & ~S_BG) ? S_BG : !(fm & ~S_GC) ? S_GC : !(fm & ~S_BDR) ? S_BDR : EF_ALL;
+    constexpr int lav_threads_gemm_huge_kernel = 512, lav_threads_gemm_big_kernel = 512;
+    (void)lav_threads_gemm_huge_kernel; (void)lav_threads_gemm_big_kernel;
 #define LAV_LAUNCH_ONE(KERN, AKC_, BKC_, F_, GRID, LDS)                                                                   \
     do {                                                                                                                  \
         static bool attr_done = false;                                                                                    \
@@ -939,7 +953,7 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
             (void)hipGetLastError();                                                                                      \
             attr_done = true;                                                                                             \
         }                                                                                                                 \
-        hipLaunchKernelGGL((KERN<AKC_, BKC_, F_>), GRID, dim3(512), LDS, s, g);                                           \
+        hipLaunchKernelGGL((KERN<AKC_, BKC_, F_>), GRID, dim3(lav_threads_##KERN), LDS, s, g);                            \
     } while (0)
 #define LAV_LAUNCH_BY_LAYOUT(KERN, F_, GRID, LDS)                                                                         \
     do {                                                                                                                  \
