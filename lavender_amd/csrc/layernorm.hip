@@ -106,64 +106,89 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         for (int k = 0; k < 8; ++k) { dg[it][k] = 0.f; db[it][k] = 0.f; cs[it][k] = 0.f; }
     const float inv_keep = a.ex.dropout_p > 0.f ? 1.0f / (1.0f - a.ex.dropout_p) : 1.0f;
 
-    for (int row = blockIdx.x * RPW + grp; row < a.rows; row += gridDim.x * RPW) {
-        const float mean = a.mean[row], rstd = a.rstd[row];
-        float xh[ITERS][8], gy[ITERS][8];
-        float s1 = 0.f, s2 = 0.f;
+    // two rows per group per trip: all loads of both rows (x, dy, the residual-stream gradient) are issued before the first
+    // reduction, which doubles the bytes in flight per wave -- the pass is latency-bound otherwise (2.9 TB/s with one row)
+    constexpr int NR = ITERS == 1 ? 2 : 1;                   // wider rows (C > 512) already carry two 16-byte chunks per lane per tensor
+    const int rstride = gridDim.x * RPW;
+    for (int row0 = blockIdx.x * RPW + grp; row0 < a.rows; row0 += NR * rstride) {
+        uint4 xu[NR][ITERS], du[NR][ITERS], au[NR][ITERS];
+        float mean[NR], rstd[NR];
+        bool live[NR];
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            int col = (it * G + gl) * 8;
-            if (col < a.C) {
-                float xv[8], dv[8];
-                uint4 u = *(const uint4*)(a.x + ln_src_off(a.geo, row, col, a.ldx));
-                unpack8(u, xv);
-                uint4 d = *(const uint4*)(a.dy + (long)row * a.lddy + col);
-                unpack8(d, dv);
-                float4 g0 = *(const float4*)(a.gamma + col), g1 = *(const float4*)(a.gamma + col + 4);
-                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        for (int q = 0; q < NR; ++q) {
+            const int row = row0 + q * rstride;
+            live[q] = row < a.rows;
+            mean[q] = live[q] ? a.mean[row] : 0.f;
+            rstd[q] = live[q] ? a.rstd[row] : 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    xh[it][k] = (xv[k] - mean) * rstd;
-                    gy[it][k] = gg[k] * dv[k];
-                    s1 += gy[it][k];
-                    s2 += gy[it][k] * xh[it][k];
-                    dg[it][k] += dv[k] * xh[it][k];
-                    db[it][k] += dv[k];
+            for (int it = 0; it < ITERS; ++it) {
+                const int col = (it * G + gl) * 8;
+                xu[q][it] = make_uint4(0, 0, 0, 0); du[q][it] = xu[q][it]; au[q][it] = xu[q][it];
+                if (live[q] && col < a.C) {
+                    xu[q][it] = *(const uint4*)(a.x + ln_src_off(a.geo, row, col, a.ldx));
+                    du[q][it] = *(const uint4*)(a.dy + (long)row * a.lddy + col);
+                    if (a.add_in) au[q][it] = *(const uint4*)(a.add_in + ln_src_off(a.geo, row, col, a.ldadd));
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { xh[it][k] = 0.f; gy[it][k] = 0.f; }
             }
         }
-        const float m1 = group_sum<G>(s1) / (float)a.C, m2 = group_sum<G>(s2) / (float)a.C;
-        const float rs = a.ex.row_scale ? a.ex.row_scale[row / a.ex.rows_per_group] : 1.0f;
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            int col = (it * G + gl) * 8;
-            if (col < a.C) {
-                float o[8];
+        for (int q = 0; q < NR; ++q) {
+            if (!live[q]) continue;
+            const int row = row0 + q * rstride;
+            float xh[ITERS][8], gy[ITERS][8];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = rstd * (gy[it][k] - m1 - xh[it][k] * m2);
-                const long doff = ln_src_off(a.geo, row, col, a.lddx);
-                if (a.add_in) {
-                    float r[8];
-                    uint4 u = *(const uint4*)(a.add_in + ln_src_off(a.geo, row, col, a.ldadd));
-                    unpack8(u, r);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) o[k] += r[k];
-                }
-                *(uint4*)(a.dx + doff) = pack8(o);
-                if (a.ex.dx2 || a.ex.colsum) {
-                    float o2[8];
+            for (int it = 0; it < ITERS; ++it) {
+                const int col = (it * G + gl) * 8;
+                if (col < a.C) {
+                    float xv[8], dv[8];
+                    unpack8(xu[q][it], xv);
+                    unpack8(du[q][it], dv);
+                    float4 g0 = *(const float4*)(a.gamma + col), g1 = *(const float4*)(a.gamma + col + 4);
+                    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        float t = o[k] * rs;
-                        if (a.ex.dropout_p > 0.f)
-                            t = lav_keep(a.ex.seed, (uint32_t)row * (uint32_t)a.C + (uint32_t)(col + k), a.thresh) ? t * inv_keep : 0.f;
-                        o2[k] = t;
-                        cs[it][k] += t;
+                        xh[it][k] = (xv[k] - mean[q]) * rstd[q];
+                        gy[it][k] = gg[k] * dv[k];
+                        s1 += gy[it][k];
+                        s2 += gy[it][k] * xh[it][k];
+                        dg[it][k] += dv[k] * xh[it][k];
+                        db[it][k] += dv[k];
                     }
-                    if (a.ex.dx2) *(uint4*)((bf16_t*)a.ex.dx2 + (long)row * a.ex.lddx2 + col) = pack8(o2);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { xh[it][k] = 0.f; gy[it][k] = 0.f; }
+                }
+            }
+            const float m1 = group_sum<G>(s1) / (float)a.C, m2 = group_sum<G>(s2) / (float)a.C;
+            const float rs = a.ex.row_scale ? a.ex.row_scale[row / a.ex.rows_per_group] : 1.0f;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int col = (it * G + gl) * 8;
+                if (col < a.C) {
+                    float o[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = rstd[q] * (gy[it][k] - m1 - xh[it][k] * m2);
+                    const long doff = ln_src_off(a.geo, row, col, a.lddx);
+                    if (a.add_in) {
+                        float r[8];
+                        unpack8(au[q][it], r);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] += r[k];
+                    }
+                    *(uint4*)(a.dx + doff) = pack8(o);
+                    if (a.ex.dx2 || a.ex.colsum) {
+                        float o2[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            float t = o[k] * rs;
+                            if (a.ex.dropout_p > 0.f)
+                                t = lav_keep(a.ex.seed, (uint32_t)row * (uint32_t)a.C + (uint32_t)(col + k), a.thresh) ? t * inv_keep : 0.f;
+                            o2[k] = t;
+                            cs[it][k] += t;
+                        }
+                        if (a.ex.dx2) *(uint4*)((bf16_t*)a.ex.dx2 + (long)row * a.ex.lddx2 + col) = pack8(o2);
+                    }
                 }
             }
         }
