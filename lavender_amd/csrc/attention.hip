@@ -119,6 +119,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                         for (int r = 0; r < 16; ++r) s[kt][r] = -INFINITY;
                         continue;
                     }
+                    if constexpr (MODE == 1) {
+                        // sequence mode: the additive key mask already holds -inf for masked / out-of-range keys
+                        const float sc = a.d.scale * LOG2E;
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const float4 ad = *(const float4*)((const float*)kinfo + k0 + 8 * r4 + 4 * hi);
+                            const float ads[4] = {ad.x, ad.y, ad.z, ad.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = fmaf(s[kt][r4 * 4 + e], sc, ads[e]);
+                                s[kt][r4 * 4 + e] = v;
+                                mx = fmaxf(mx, v);
+                            }
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const int kb = k0 + 8 * r4 + 4 * hi;           // 4 consecutive keys
@@ -159,11 +175,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(s[kt][r] - m_use); l_run += p[r]; }
                     if (MODE == 1 && a.d.dropout_p > 0.f) {
+                        // one hash per key PAIR (this lane holds keys kb..kb+3 of each group of 8): index = (row, key >> 1)
                         const float inv = 1.f / (1.f - a.d.dropout_p);
-                        const uint32_t base = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)q) * (uint32_t)N + (uint32_t)(kc0 + k0 + 4 * hi);
+                        const uint32_t pb = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)q) * (uint32_t)a.NH +
+                                            (uint32_t)((kc0 + k0 + 4 * hi) >> 1);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            p[r] = lav_keep(a.d.seed, base + (uint32_t)((r & 3) + 8 * (r >> 2)), a.thresh) ? p[r] * inv : 0.f;
+                        for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                            for (int e2 = 0; e2 < 2; ++e2) {
+                                const uint32_t h = lav_hash32(a.d.seed, pb + (uint32_t)(4 * r4 + e2));
+                                const int r = r4 * 4 + 2 * e2;
+                                p[r] = (h & 0xffffu) >= a.thresh16 ? p[r] * inv : 0.f;
+                                p[r + 1] = (h >> 16) >= a.thresh16 ? p[r + 1] * inv : 0.f;
+                            }
                     }
 #pragma unroll
                     for (int sl = 0; sl < 2; ++sl) {
@@ -308,6 +332,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a, float* del
                 float ds[16];
                 const float inv = (MODE == 1 && a.d.dropout_p > 0.f) ? 1.f / (1.f - a.d.dropout_p) : 1.f;
                 const uint32_t base = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)q) * (uint32_t)N + (uint32_t)kc0;
+                if constexpr (MODE == 1) {
+                    // lean sequence path: masks folded into the additive key term (-inf) and the row's lse (+inf for a padded
+                    // query), one dropout hash per key pair
+                    const float sc = a.d.scale * LOG2E;
+                    const float lse_q = q_ok ? lse : INFINITY;
+                    const uint32_t pb = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)q) * (uint32_t)a.NH +
+                                        (uint32_t)((kc0 + k0 + 4 * hi) >> 1);
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float4 ad = *(const float4*)((const float*)kinfo + k0 + 8 * r4 + 4 * hi);
+                        const float ads[4] = {ad.x, ad.y, ad.z, ad.w};
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const uint32_t h = lav_hash32(a.d.seed, pb + (uint32_t)(4 * r4 + e2));   // p = 0: thresh16 = 0 keeps everything
+                            const float m0 = (h & 0xffffu) >= a.thresh16 ? inv : 0.f;
+                            const float m1 = (h >> 16) >= a.thresh16 ? inv : 0.f;
+                            const int r = r4 * 4 + 2 * e2;
+                            const float p0 = fast_exp2(fmaf(s[r], sc, ads[2 * e2]) - lse_q);
+                            const float p1 = fast_exp2(fmaf(s[r + 1], sc, ads[2 * e2 + 1]) - lse_q);
+                            ds[r] = p0 * (dp[r] * m0 - dl);
+                            ds[r + 1] = p1 * (dp[r + 1] * m1 - dl);
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int kb = k0 + 8 * r4 + 4 * hi;
@@ -376,7 +424,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a, float* del
 //   dV^T = dO^T P~   (P~ = dropout(P)) ;  dK^T = Q^T dS * scale
 // ------------------------------------------------------------------------------------------------
 template <int HD, int MODE, int QL>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a, const float* delta_in) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a, const float* delta_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;                                  // K-type: A operand of S
     char* Qv = Qs + QL * HD * 2;                      // V-type: tr-read A operand of dK^T
@@ -411,6 +459,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a, const flo
                 if (a.d.key_mask && a.d.key_mask[(long)prob * N + key] == 0) k_add = -INFINITY;
             }
         }
+        if (MODE == 1 && !k_ok) k_add = -INFINITY;          // padded key lanes: P = 0 without a per-element validity test
         bf16x8 kf[HD / 16], vf[HD / 16];
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
@@ -454,6 +503,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a, const flo
                         if (MODE == 0) { TokInfo t = win_token(a, prob, q); info = t.code | (t.region << 16); }
                         l = a.lse[(long)blockIdx.x * a.Npad + q];
                         dl = delta_in[(long)blockIdx.x * a.Npad + q];
+                    } else if (MODE == 1) {
+                        l = INFINITY;                           // padded query rows: P = exp2(v - inf) = 0
                     }
                     qinfo[row] = info; qlse[row] = l; qdl[row] = dl;
                 }
@@ -474,6 +525,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a, const flo
                 }
                 float pd[16], ds[16];
                 const float inv = (MODE == 1 && a.d.dropout_p > 0.f) ? 1.f / (1.f - a.d.dropout_p) : 1.f;
+                if constexpr (MODE == 1) {
+                    // lean sequence path (see the dQ pass); a lane holds ONE key here, so the pair hash is indexed by
+                    // (query row, key >> 1) and this lane takes the half selected by its key's parity
+                    const float sc = a.d.scale * LOG2E;
+                    const uint32_t nh = (uint32_t)a.NH;
+                    const uint32_t rb0 = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)(qc0 + q0 + 4 * hi)) * nh + (uint32_t)(key >> 1);
+                    const uint32_t sh = (uint32_t)(key & 1) * 16u;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int qb = q0 + 8 * r4 + 4 * hi;
+                        const float4 l4 = *(const float4*)(qlse + qb);
+                        const float4 d4 = *(const float4*)(qdl + qb);
+                        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+                        const float dls[4] = {d4.x, d4.y, d4.z, d4.w};
+                        const uint32_t rb = rb0 + (uint32_t)(8 * r4) * nh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = r4 * 4 + e;
+                            const float p = fast_exp2(fmaf(s[r], sc, k_add) - ls[e]);
+                            const uint32_t h = lav_hash32(a.d.seed, rb + (uint32_t)e * nh);   // p = 0: thresh16 = 0 keeps everything
+                            const float m = ((h >> sh) & 0xffffu) >= a.thresh16 ? inv : 0.f;
+                            pd[r] = p * m;
+                            ds[r] = p * (dp[r] * m - dls[e]);
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int qb = q0 + 8 * r4 + 4 * hi;
@@ -584,6 +661,8 @@ int attn_setup(const lav_attn_desc* d, AttnArgs& a, int& problems) {
     a.nqt = (a.N + 31) / 32;
     a.Npad = a.nqt * 32;
     a.thresh = lav_drop_thresh(d->dropout_p);
+    a.thresh16 = lav_drop_thresh16(d->dropout_p);
+    a.NH = (a.N + 1) / 2;
     return LAV_OK;
 }
 
@@ -599,7 +678,8 @@ static void set_lds(K kern, size_t bytes) {
 }
 
 #define WIN_KL 256
-#define SEQ_KL 288
+#define SEQ_KL_FWD 288   // forward: K/V of a whole fusion sequence (L <= 288) staged once, two blocks per CU
+#define SEQ_KL 128       // backward dQ pass: 128-key chunks -> 48 KB of LDS, the register file (not LDS) sets the occupancy
 
 extern "C" int lav_attention_fwd(void* stream, const lav_attn_desc* d, const void* qkv, void* out, float* lse) {
     AttnArgs a; int problems = 0;
@@ -608,7 +688,7 @@ extern "C" int lav_attention_fwd(void* stream, const lav_attn_desc* d, const voi
     a.qkv = (const bf16_t*)qkv; a.o_w = (bf16_t*)out; a.lse = lse;
     if (d->mode == 0 && d->comb) return win_persistent_fwd(stream, a);
     hipStream_t s = (hipStream_t)stream;
-    const int KL = d->mode == 0 ? WIN_KL : SEQ_KL;
+    const int KL = d->mode == 0 ? WIN_KL : SEQ_KL_FWD;
     const int qgroups = (a.nqt + 3) / 4;
     if (a.N <= KL) { a.R = qgroups; } else { a.R = 1; }
     dim3 grid(problems * d->heads, a.N <= KL ? 1 : qgroups), block(256);
@@ -617,14 +697,14 @@ extern "C" int lav_attention_fwd(void* stream, const lav_attn_desc* d, const voi
         set_lds(attn_fwd_kernel<32, 0, 8, WIN_KL>, lds);
         hipLaunchKernelGGL((attn_fwd_kernel<32, 0, 8, WIN_KL>), grid, block, lds, s, a);
     } else {
-        size_t lds = (size_t)SEQ_KL * 64 * 2 * 2 + SEQ_KL * 4;
-        set_lds(attn_fwd_kernel<64, 1, 3, SEQ_KL>, lds);
-        hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 3, SEQ_KL>), grid, block, lds, s, a);
+        size_t lds = (size_t)SEQ_KL_FWD * 64 * 2 * 2 + SEQ_KL_FWD * 4;
+        set_lds(attn_fwd_kernel<64, 1, 3, SEQ_KL_FWD>, lds);
+        hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 3, SEQ_KL_FWD>), grid, block, lds, s, a);
     }
     return lav_check_launch("lav_attention_fwd");
 }
 
-#define SEQ_QL 256
+#define SEQ_QL 128       // backward dK/dV pass: 128-query chunks (4 staged copies = 64 KB): two blocks per CU instead of one
 
 extern "C" int lav_attention_bwd(void* stream, const lav_attn_desc* d, const void* qkv, const void* out, const void* dout,
                                  const float* lse, void* dqkv, float* dbias_table) {

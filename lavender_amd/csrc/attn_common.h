@@ -20,6 +20,8 @@ struct AttnArgs {
     int tbl_rows, tbl_const, cstride_d, cstride_h;   // bias-table geometry
     int R;            // 32-row tiles per wave
     uint32_t thresh;
+    uint32_t thresh16; // sequence mode: dropout threshold on 16-bit hash halves (one hash per key pair)
+    int NH;           // ceil(N/2): key pairs per query row
     int nWs, tps;     // windows per sample, tokens per sample (fast window path)
 };
 

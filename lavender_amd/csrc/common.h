@@ -84,6 +84,16 @@ __device__ __forceinline__ bool lav_keep(uint32_t seed, uint32_t idx, uint32_t t
     h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
     return h >= thresh;                           // P(keep) = 1 - thresh / 2^32
 }
+// two keep decisions from one hash (the 16-bit halves): used where a lane holds both elements of an index pair
+__device__ __forceinline__ uint32_t lav_hash32(uint32_t seed, uint32_t idx) {
+    uint32_t h = idx * 0x9E3779B1u + seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
+    return h;
+}
+static inline uint32_t lav_drop_thresh16(float p) {       // P(keep) = 1 - thresh16 / 65536
+    double t = (double)p * 65536.0 + 0.5;
+    return t >= 65535.0 ? 65535u : (uint32_t)t;
+}
 static inline uint32_t lav_drop_thresh(float p) {
     double t = (double)p * 4294967296.0;
     return t >= 4294967295.0 ? 4294967295u : (uint32_t)t;

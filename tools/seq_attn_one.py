@@ -16,3 +16,15 @@ for _ in range(3):
     att.fwd(qkv, out, lse)
     att.bwd(qkv, out, dout, lse, dqkv, None)
 torch.cuda.synchronize()
+
+
+def _t(f, n=10):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+print(f"n={n} L={L}: fwd {_t(lambda: att.fwd(qkv, out, lse)):.1f} us, bwd (dq + dkv) {_t(lambda: att.bwd(qkv, out, dout, lse, dqkv, None)):.1f} us")
