@@ -182,8 +182,13 @@ __global__ __launch_bounds__(512) void win_fwd_p(AttnArgs a, int bsplit) {
 // LDS float atomics are avoided entirely (measured: a 64-lane ds_add_f32 retires in ~200 cycles): the final
 // flush is a half-wave-masked read-modify-write into a wave-private LDS copy of the table.
 // ------------------------------------------------------------------------------------------------------
-template <bool DBIAS>
-__global__ __launch_bounds__(256) void win_dq_p(AttnArgs a, int bsplit, float* delta_out) {
+// NW = 4: one wave per SIMD, two query tiles per wave (512 registers each).  NW = 8: two waves per SIMD, ONE query tile
+// per wave (<= 256 registers: 128 for the resident dS sums), so the MFMA -> VALU -> MFMA chains of one wave are
+// covered by the other; the two wave groups flush into the same four LDS tables one after the other.
+template <bool DBIAS, int NW>
+__global__ __launch_bounds__(NW * 64) void win_dq_p(AttnArgs a, int bsplit, float* delta_out) {
+    constexpr int NQ = 8 / NW;                           // query tiles per wave
+    constexpr int NTHR = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][K(A) 16K | K(tr) 16K | V(A) 16K] + kcode + 4 x dtbl
     WinGeo g;
     if (!win_geo(a, bsplit, g)) return;
@@ -195,18 +200,18 @@ __global__ __launch_bounds__(256) void win_dq_p(AttnArgs a, int bsplit, float* d
     const bf16_t* qkv = a.qkv;
     const float sc = a.d.scale * LOG2E;
 
-    if (DBIAS) for (int r = tid; r < 4 * a.tbl_rows; r += 256) dtbl_all[r] = 0.f;
-    {
+    if (DBIAS) for (int r = tid; r < 4 * a.tbl_rows; r += NTHR) dtbl_all[r] = 0.f;
+    if (tid < 256) {
         const int i = tid;
         kcode[i] = i < N ? (i / (a.d.ww * a.d.wh)) * a.cstride_d + ((i / a.d.ww) % a.d.wh) * a.cstride_h + (i % a.d.ww) : 0;
         const int rel = a.d.tok_table[g.ws * 256 + i];
         srel_l[i] = rel < 0 ? 0 : rel;      // padded keys read a valid row: their scores are masked to -inf-like by the bias table
     }
     __syncthreads();
-    int qrel[2]; bool q_ok[2];
+    int qrel[NQ]; bool q_ok[NQ];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        qrel[qi] = a.d.tok_table[g.ws * 256 + (wave + 4 * qi) * 32 + j];
+    for (int qi = 0; qi < NQ; ++qi) {
+        qrel[qi] = a.d.tok_table[g.ws * 256 + (wave + NW * qi) * 32 + j];
         q_ok[qi] = qrel[qi] >= 0;
     }
     const int ntile = (N + 31) >> 5;
@@ -221,24 +226,24 @@ __global__ __launch_bounds__(256) void win_dq_p(AttnArgs a, int bsplit, float* d
         for (int e = 0; e < 8; ++e) e8[e] = (j == 16 * sl + 8 * (e >> 2) + 4 * hi + (e & 3)) ? 1.f : 0.f;
         onehot[sl] = pack_frag(e8);
     }
-    f32x16 dsa[2][8];
+    f32x16 dsa[NQ][8];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
+    for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dsa[qi][kt][r] = 0.f;
 
-    uint4 qn[2][2], gn[2][2], on[2][2];
-    float lse_n[2] = {0.f, 0.f};
+    uint4 qn[NQ][2], gn[NQ][2], on[NQ][2];
+    float lse_n[NQ];
     // K (two layouts) and V of window b go straight from HBM/L2 into LDS buffer `buf` (global_load_lds, 1 KB per
     // wave-instruction, no staging registers); the swizzle of the ds_read_b128 layout is applied to the SOURCE slot
     auto issue_kv = [&](int b, int buf) {
         const long base = (long)b * a.tps;
         char* B0 = smem + buf * 49152;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int t = wave * 12 + i;
+        for (int i = 0; i < 48 / NW; ++i) {
+            const int t = wave * (48 / NW) + i;
             const int cpy = t >> 4, chunk = t & 15;
             const int rel = srel_l[chunk * 16 + (lane >> 2)];
             const int lslot = cpy == 1 ? (lane & 3) : ((lane & 3) ^ ((lane >> 4) & 3));
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void win_dq_p(AttnArgs a, int bsplit, float* d
     auto load = [&](int b) {
         const long base = (long)b * a.tps;
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
+        for (int qi = 0; qi < NQ; ++qi) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 qn[qi][ks] = make_uint4(0, 0, 0, 0); gn[qi][ks] = qn[qi][ks]; on[qi][ks] = qn[qi][ks];
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(256) void win_dq_p(AttnArgs a, int bsplit, float* d
                     on[qi][ks] = *(const uint4*)(a.out + row * C + off);
                 }
             }
-            lse_n[qi] = q_ok[qi] ? a.lse[((long)(b * a.nWs + g.ws) * a.d.heads + g.head) * a.Npad + (wave + 4 * qi) * 32 + j] : 0.f;
+            lse_n[qi] = q_ok[qi] ? a.lse[((long)(b * a.nWs + g.ws) * a.d.heads + g.head) * a.Npad + (wave + NW * qi) * 32 + j] : 0.f;
         }
     };
     issue_kv(g.b0, 0);
@@ -274,10 +279,11 @@ __global__ __launch_bounds__(256) void win_dq_p(AttnArgs a, int bsplit, float* d
         const char* Ks = smem + cur * 49152;
         const char* Kv = Ks + 16384;
         const char* Vs = Ks + 32768;
-        bf16x8 qf[2][2], dof[2][2];
-        float dl[2], lse[2];
+        if (NW == 8 && b > g.b0) load(b);
+        bf16x8 qf[NQ][2], dof[NQ][2];
+        float dl[NQ], lse[NQ];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
+        for (int qi = 0; qi < NQ; ++qi) {
             float d = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -290,13 +296,16 @@ __global__ __launch_bounds__(256) void win_dq_p(AttnArgs a, int bsplit, float* d
             d += __shfl_xor(d, 32, 64);
             dl[qi] = d; lse[qi] = lse_n[qi];
             if (q_ok[qi] && hi == 0)
-                delta_out[((long)(b * a.nWs + g.ws) * a.d.heads + g.head) * a.Npad + (wave + 4 * qi) * 32 + j] = d;
+                delta_out[((long)(b * a.nWs + g.ws) * a.d.heads + g.head) * a.Npad + (wave + NW * qi) * 32 + j] = d;
         }
-        if (b + 1 < g.b1) { issue_kv(b + 1, cur ^ 1); load(b + 1); }
+        if (b + 1 < g.b1) {
+            issue_kv(b + 1, cur ^ 1);
+            if (NW == 4) load(b + 1);                     // NW == 8: no register prefetch (the second wave of the SIMD covers the latency)
+        }
 
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            const int qt = wave + 4 * qi;
+        for (int qi = 0; qi < NQ; ++qi) {
+            const int qt = wave + NW * qi;
             if (qt >= ntile) break;
             const bf16_t* comb = comb0 + (long)qt * 8 * 1024;
             f32x16 dq;
@@ -350,30 +359,35 @@ __global__ __launch_bounds__(256) void win_dq_p(AttnArgs a, int bsplit, float* d
     // Within one half-wave the 32 queries are distinct tokens and the key is fixed, so the 32 indices are distinct:
     // a plain read-modify-write per half is race-free.  The two halves (key, key + 4) are done one after the other.
     if (DBIAS) {
-        float* dtbl = dtbl_all + wave * a.tbl_rows;
+        float* dtbl = dtbl_all + (wave & 3) * a.tbl_rows;
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            const int qt = wave + 4 * qi;
-            if (qt >= ntile) break;
-            const int qc = kcode[qt * 32 + j] + a.tbl_const;
+        for (int grp = 0; grp < NW / 4; ++grp) {             // wave groups take turns on the four tables
+            if (grp > 0) __syncthreads();
+            if ((wave >> 2) != grp) continue;
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) {
-                if (kt >= ntile) break;
+            for (int qi = 0; qi < NQ; ++qi) {
+                const int qt = wave + NW * qi;
+                if (qt >= ntile) break;
+                const int qc = kcode[qt * 32 + j] + a.tbl_const;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = kt * 32 + tile_row(r, hi);
-                    const int idx = qc - kcode[k];
-                    const bool ok = q_ok[qi] && k < N;
+                for (int kt = 0; kt < 8; ++kt) {
+                    if (kt >= ntile) break;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        if (hi == h && ok) dtbl[idx] += dsa[qi][kt][r];
-                        __builtin_amdgcn_wave_barrier();
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = kt * 32 + tile_row(r, hi);
+                        const int idx = qc - kcode[k];
+                        const bool ok = q_ok[qi] && k < N;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            if (hi == h && ok) dtbl[idx] += dsa[qi][kt][r];
+                            __builtin_amdgcn_wave_barrier();
+                        }
                     }
                 }
             }
         }
         __syncthreads();
-        for (int r = tid; r < a.tbl_rows; r += 256) {
+        for (int r = tid; r < a.tbl_rows; r += NTHR) {
             const float v = dtbl_all[r] + dtbl_all[a.tbl_rows + r] + dtbl_all[2 * a.tbl_rows + r] + dtbl_all[3 * a.tbl_rows + r];
             if (v != 0.f) atomicAdd(a.dbias + (long)r * a.d.heads + g.head, v);
         }
@@ -594,10 +608,15 @@ int win_persistent_fwd(void* stream, const AttnArgs& a) {
 int win_persistent_bwd(void* stream, const AttnArgs& a, float* delta) {
     const int bs = pick_bsplit(a);
     const size_t lds1 = 2 * 49152 + 2048 + (size_t)a.tbl_rows * 16;
-    big_lds(win_dq_p<true>, lds1);
-    big_lds(win_dq_p<false>, lds1);
-    if (a.dbias) hipLaunchKernelGGL(win_dq_p<true>, dim3(a.d.heads * a.nWs * bs), dim3(256), lds1, (hipStream_t)stream, a, bs, delta);
-    else hipLaunchKernelGGL(win_dq_p<false>, dim3(a.d.heads * a.nWs * bs), dim3(256), lds1, (hipStream_t)stream, a, bs, delta);
+    // with the bias-table gradient the resident dS sums need the 512-register budget of one wave per SIMD (the 8-wave
+    // variant spills in its inner loop: 375 vs 309 us on the stage-2 shape); without it two waves per SIMD win (202 vs 230 us)
+    if (a.dbias) {
+        big_lds((win_dq_p<true, 4>), lds1);
+        hipLaunchKernelGGL((win_dq_p<true, 4>), dim3(a.d.heads * a.nWs * bs), dim3(256), lds1, (hipStream_t)stream, a, bs, delta);
+    } else {
+        big_lds((win_dq_p<false, 8>), lds1);
+        hipLaunchKernelGGL((win_dq_p<false, 8>), dim3(a.d.heads * a.nWs * bs), dim3(512), lds1, (hipStream_t)stream, a, bs, delta);
+    }
     const size_t lds2 = 2 * (65536 + 2048);
     big_lds(win_dkv_p, lds2);
     hipLaunchKernelGGL(win_dkv_p, dim3(a.d.heads * a.nWs * bs), dim3(512), lds2, (hipStream_t)stream, a, bs, (const float*)delta);
