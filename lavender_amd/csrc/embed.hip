@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void video_embed_fwd_kernel(int B, int T, int 
     if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
 }
 
-// backward: one block per token position p' (0 = cls): it walks the B*T rows that share the position embedding, so
-// d_pos[p'] is a private register sum (one atomic per element per block instead of one per row), d_len[t] and
-// dgamma / dbeta are accumulated per block before touching global memory.
+// backward: one block per (token position p' (0 = cls), frame t): it walks the B rows that share the position and length
+// embeddings, so d_pos[p'], d_len[t], dgamma and dbeta are private register sums (one atomic per element per block
+// instead of one per row).
 __global__ __launch_bounds__(256) void video_embed_bwd_kernel(int B, int T, int hw, int Hd, const bf16_t* __restrict__ dout, long seq_rows,
                                                              const bf16_t* __restrict__ feat, const float* cls, const float* pos,
                                                              const float* len, const float* gamma, const float* mean_i,
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void video_embed_bwd_kernel(int B, int T, int 
                                                              float* d_len, float* dgamma, float* dbeta) {
     __shared__ float red[2][4];
     const int P = 1 + hw, pp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t_only = blockIdx.y;                        // one block per (position, frame): 5x more blocks than one per position
     constexpr int MAXJ = 4;                               // columns per thread: Hd <= 1024
     float xpos[MAXJ], gam[MAXJ], a_pos[MAXJ], a_g[MAXJ], a_b[MAXJ];
 #pragma unroll
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void video_embed_bwd_kernel(int B, int T, int 
         gam[j] = ok ? gamma[c] : 0.f;
         a_pos[j] = a_g[j] = a_b[j] = 0.f;
     }
-    for (int t = 0; t < T; ++t) {
+    for (int t = t_only; t == t_only; ++t) {
         float a_len[MAXJ] = {0.f, 0.f, 0.f, 0.f};
         float lent[MAXJ];
 #pragma unroll
@@ -180,7 +181,7 @@ extern "C" int lav_video_embed_bwd(void* stream, int B, int T, int hw, int Hd, c
                                    float* dgamma, float* dbeta) {
     LAV_REQUIRE(B > 0 && T > 0 && hw > 0 && Hd % 8 == 0 && Hd <= 1024, "lav_video_embed_bwd: bad shape (Hd=%d)", Hd);
     LAV_REQUIRE(dout && feat && dfeat && d_cls && d_pos && d_len && dgamma && dbeta, "lav_video_embed_bwd: null pointer");
-    hipLaunchKernelGGL(video_embed_bwd_kernel, dim3(1 + hw), dim3(256), 0, (hipStream_t)stream, B, T, hw, Hd,
+    hipLaunchKernelGGL(video_embed_bwd_kernel, dim3(1 + hw, T), dim3(256), 0, (hipStream_t)stream, B, T, hw, Hd,
                        (const bf16_t*)dout, seq_rows, (const bf16_t*)feat, emb_cls, emb_pos, emb_len, gamma, mean, rstd,
                        (bf16_t*)dfeat, d_cls, d_pos, d_len, dgamma, dbeta);
     return lav_check_launch("lav_video_embed_bwd");
@@ -235,52 +236,86 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(int n, int X, int H
     if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
 }
 
+// backward: one block per (token position, group of sequences): the rows of a block share the position embedding, so
+// d_pos[x], d_type0, dgamma and dbeta are accumulated in registers, merged across the four waves through LDS and
+// flushed with ONE atomic per column per block (the per-row version issued 5 same-address atomics per element);
+// only the word-embedding rows are scattered per row.
 template <int MAXC>
 __global__ __launch_bounds__(256) void text_embed_bwd_kernel(int n, int X, int Hd, const int64_t* ids, const bf16_t* dout, const float* word,
                                                             const float* pos, const float* type0, const float* gamma,
                                                             const float* mean_i, const float* rstd_i, float p, uint32_t seed,
                                                             uint32_t thresh, float* d_word, float* d_pos, float* d_type0,
                                                             float* dgamma, float* dbeta) {
-    const int lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= (long)n * X) return;
-    const int xp = r % X;
-    const long id = ids[r];
-    const float mean = mean_i[r], rstd = rstd_i[r];
+    extern __shared__ float red[];                        // [4 waves][3][Hd]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xp = blockIdx.x;
+    const int per = (n + gridDim.y - 1) / gridDim.y;
+    const int s0 = blockIdx.y * per, s1e = min(n, s0 + per);
     const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    float xh[MAXC][8], gy[MAXC][8];
-    float s1 = 0.f, s2 = 0.f;
+    float a_g[MAXC][8], a_b[MAXC][8], a_x[MAXC][8];
 #pragma unroll
-    for (int it = 0; it < MAXC; ++it) {
-        const int col = (it * 64 + lane) * 8;
-        if (col < Hd) {
-            float d[8];
-            uint4 du = *(const uint4*)(dout + r * Hd + col); unpack8(du, d);
+    for (int it = 0; it < MAXC; ++it)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (p > 0.f) d[k] = lav_keep(seed, (uint32_t)r * (uint32_t)Hd + (uint32_t)(col + k), thresh) ? d[k] * inv : 0.f;
-                const float xv = word[id * Hd + col + k] + pos[(long)xp * Hd + col + k] + type0[col + k];
-                xh[it][k] = (xv - mean) * rstd;
-                gy[it][k] = gamma[col + k] * d[k];
-                s1 += gy[it][k]; s2 += gy[it][k] * xh[it][k];
-                atomicAdd(dgamma + col + k, d[k] * xh[it][k]);
-                atomicAdd(dbeta + col + k, d[k]);
+        for (int k = 0; k < 8; ++k) { a_g[it][k] = 0.f; a_b[it][k] = 0.f; a_x[it][k] = 0.f; }
+    for (int sq = s0 + wave; sq < s1e; sq += 4) {
+        const long r = (long)sq * X + xp;
+        const long id = ids[r];
+        const float mean = mean_i[r], rstd = rstd_i[r];
+        float xh[MAXC][8], gy[MAXC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXC; ++it) {
+            const int col = (it * 64 + lane) * 8;
+            if (col < Hd) {
+                float d[8];
+                uint4 du = *(const uint4*)(dout + r * Hd + col); unpack8(du, d);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (p > 0.f) d[k] = lav_keep(seed, (uint32_t)r * (uint32_t)Hd + (uint32_t)(col + k), thresh) ? d[k] * inv : 0.f;
+                    const float xv = word[id * Hd + col + k] + pos[(long)xp * Hd + col + k] + type0[col + k];
+                    xh[it][k] = (xv - mean) * rstd;
+                    gy[it][k] = gamma[col + k] * d[k];
+                    s1 += gy[it][k]; s2 += gy[it][k] * xh[it][k];
+                    a_g[it][k] += d[k] * xh[it][k];
+                    a_b[it][k] += d[k];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / Hd, m2 = wave_sum(s2) / Hd;
+#pragma unroll
+        for (int it = 0; it < MAXC; ++it) {
+            const int col = (it * 64 + lane) * 8;
+            if (col < Hd) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float dx = rstd * (gy[it][k] - m1 - xh[it][k] * m2);
+                    a_x[it][k] += dx;
+                    atomicAdd(d_word + id * Hd + col + k, dx);
+                }
             }
         }
     }
-    const float m1 = wave_sum(s1) / Hd, m2 = wave_sum(s2) / Hd;
 #pragma unroll
     for (int it = 0; it < MAXC; ++it) {
         const int col = (it * 64 + lane) * 8;
         if (col < Hd) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float dx = rstd * (gy[it][k] - m1 - xh[it][k] * m2);
-                atomicAdd(d_word + id * Hd + col + k, dx);
-                atomicAdd(d_pos + (long)xp * Hd + col + k, dx);
-                atomicAdd(d_type0 + col + k, dx);
+                red[(wave * 3 + 0) * Hd + col + k] = a_g[it][k];
+                red[(wave * 3 + 1) * Hd + col + k] = a_b[it][k];
+                red[(wave * 3 + 2) * Hd + col + k] = a_x[it][k];
             }
         }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Hd; c += 256) {
+        float g = 0.f, bsum = 0.f, x = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { g += red[(w * 3 + 0) * Hd + c]; bsum += red[(w * 3 + 1) * Hd + c]; x += red[(w * 3 + 2) * Hd + c]; }
+        atomicAdd(dgamma + c, g);
+        atomicAdd(dbeta + c, bsum);
+        atomicAdd(d_pos + (long)xp * Hd + c, x);
+        atomicAdd(d_type0 + c, x);
     }
 }
 
@@ -302,7 +337,9 @@ extern "C" int lav_text_embed_bwd(void* stream, int n, int X, int Hd, const int6
     LAV_REQUIRE(n > 0 && X > 0 && Hd % 8 == 0 && Hd <= 1024, "lav_text_embed_bwd: bad shape");
     LAV_REQUIRE(ids && dout && d_word && d_pos && d_type0 && dgamma && dbeta, "lav_text_embed_bwd: null pointer");
     long rows = (long)n * X;
-    hipLaunchKernelGGL(text_embed_bwd_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, X, Hd, ids,
+    const int groups = n >= 32 ? 8 : (n >= 8 ? 2 : 1);
+    (void)rows;
+    hipLaunchKernelGGL(text_embed_bwd_kernel<2>, dim3(X, groups), dim3(256), (size_t)12 * Hd * sizeof(float), (hipStream_t)stream, n, X, Hd, ids,
                        (const bf16_t*)dout, word, pos, type0, gamma, mean, rstd, dropout_p, seed, lav_drop_thresh(dropout_p), d_word,
                        d_pos, d_type0, dgamma, dbeta);
     return lav_check_launch("lav_text_embed_bwd");
