@@ -18,6 +18,7 @@ import torch
 from . import hip as K
 
 ALIGN = 64
+SLACK = 64 * 1024
 _QKV = re.compile(r"(.*attention\.self)\.(query|key|value)\.(weight|bias)$")
 
 
@@ -61,8 +62,11 @@ class ParamArena:
             self.numels[n] = p.numel()
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
-        self.master = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self.half = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        # SLACK zero elements past the last parameter: a GEMM may read a weight matrix with its row count rounded up to the
+        # k-tile (the vocabulary projection as a (30528, H) operand) without leaving the buffer; never written, never stepped
+        self.master = torch.zeros(off + SLACK, dtype=torch.float32, device=self.device)[:off]
+        self.half_full = torch.zeros(off + SLACK, dtype=torch.bfloat16, device=self.device)
+        self.half = self.half_full[:off]
         self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
         grp = torch.zeros(off // ALIGN, dtype=torch.uint8)
         self.params = {}

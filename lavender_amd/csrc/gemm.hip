@@ -197,7 +197,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         for (int x = 0; x < 8; ++x)
             if (x < ncols) bias[x] = e.bias[gcol + x];
     }
-    const bool full = GEN ? ncols == 8 : true;     // specialised variants are only dispatched when N % 8 == 0
+    // specialised variants are only dispatched when N % 8 == 0: a chunk is whole or outside the matrix, so past the
+    // "outside" test every access is a full 16-byte one (compile-time) -- the preloads below run BEFORE that test
+    const bool full = GEN ? ncols == 8 : true;
+    const bool inside = GEN ? ncols == 8 : ncols > 0;
     constexpr int NIT = ROWS / (NTHR / 16);
     constexpr int GRP = 4;                                 // rows handled together: their gelu_in / residual loads are
     static_assert(NIT % GRP == 0, "epilogue row grouping");  // issued back-to-back so HBM latency is paid once per group
@@ -208,7 +211,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         for (int u = 0; u < GRP; ++u) {
             const int grow = m0 + (etid >> 4) + (NTHR / 16) * (j0 + u);
             pre_g[u] = make_uint4(0, 0, 0, 0); pre_r[u] = pre_g[u];
-            if (full && grow < g.M) {
+            if (inside && grow < g.M) {
                 if (has_gin) pre_g[u] = *(const uint4*)((const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol);
                 if (has_res) pre_r[u] = *(const uint4*)((const bf16_t*)e.residual + (long)grow * e.ldr + gcol);
             }
@@ -877,14 +880,14 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 }
 
 // split-K of a forward / input-gradient GEMM (bf16 output, no epilogue): C = bf16(sum_s ws[s]); 8 columns per thread
-__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ ws, int splits, int tiles, int tiles_n, int M, int N,
-                                                                bf16_t* __restrict__ C, long ldc) {
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ ws, int splits, int tiles, int tiles_n, int rpt,
+                                                                int M, int N, bf16_t* __restrict__ C, long ldc) {
     const int n8 = N >> 3;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)M * n8) return;
     const int row = (int)(idx / n8), col = (int)(idx % n8) * 8;
-    const long off = ((long)(row / BM) * tiles_n + col / BN) * (BM * BN) + (row % BM) * BN + (col % BN);
-    const long stride = (long)tiles * (BM * BN);
+    const long off = ((long)(row / rpt) * tiles_n + col / BN) * (rpt * BN) + (row % rpt) * BN + (col % BN);
+    const long stride = (long)tiles * (rpt * BN);
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int sp = 0; sp < splits; ++sp) {
         const float4 a = *(const float4*)(ws + (long)sp * stride + off), b = *(const float4*)(ws + (long)sp * stride + off + 4);
@@ -1012,17 +1015,24 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     }
     if (layout != 2) {
         const bool sk = splits > 1 && g.e.out_mode == 0;     // under-filled long-K problem (vocabulary contraction): workspace split-K
+        const bool sk_huge = sk && (K % BKT) == 0 && (kps % BKT) == 0 && M >= 256 && (N % 256) == 0 && !lav_gemm_force_small;
+        const int rpt = sk_huge ? BIG_BM : BM;
+        const int ws_tiles = ((M + rpt - 1) / rpt) * ((N + BN - 1) / BN);
         if (sk) {
-            g.ws = splitk_workspace((size_t)splits * tiles * BM * BN * sizeof(float));
+            g.ws = splitk_workspace((size_t)splits * ws_tiles * rpt * BN * sizeof(float));
             LAV_REQUIRE(g.ws, "lav_gemm_bf16: split-K workspace allocation failed");
-            g.ws_tiles = tiles;
+            g.ws_tiles = ws_tiles;
         }
-        if (layout == 0) hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, block, GEMM_LDS_BYTES, s, g);
+        if (sk_huge) {
+            const dim3 hg((unsigned)(((M + BIG_BM - 1) / BIG_BM) * (N / 256) * splits));
+            if (layout == 0) LAV_LAUNCH_ONE(gemm_huge_kernel, true, true, EF_ALL, hg, HUGE_LDS);
+            else LAV_LAUNCH_ONE(gemm_huge_kernel, true, false, EF_ALL, hg, HUGE_LDS);
+        } else if (layout == 0) hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, block, GEMM_LDS_BYTES, s, g);
         else hipLaunchKernelGGL((gemm_kernel<true, false, 1>), grid, block, GEMM_LDS_BYTES, s, g);
         if (sk) {
             const long n = (long)M * (N / 8);
-            hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g.ws, splits, tiles,
-                               (N + BN - 1) / BN, M, N, (bf16_t*)C, ldc);
+            hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g.ws, splits, ws_tiles,
+                               (N + BN - 1) / BN, rpt, M, N, (bf16_t*)C, ldc);
         }
     } else {
         // ---- weight gradients -------------------------------------------------------------------------------------

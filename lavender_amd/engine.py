@@ -405,7 +405,11 @@ class MLMHeadFn(torch.autograd.Function):
             pad[:, :V].copy_(d2)
             d2 = pad[:, :V]
         K.gemm(2, d2, tn, V, Hd, R, out=G(dec.weight), accumulate=True, splits=K.splits_for(V, Hd, R), rowsum_a=G(dec.bias))
-        d_tn = K.gemm(1, d2, W16(dec.weight), R, Hd, V, splits=K.splits_nn(R, Hd, V))
+        # contraction over the vocabulary, rounded up to the row stride of the gradient buffer (30528 = 477 k-tiles): its
+        # padding columns are zeros (written by the loss kernel) and the weight rows past V lie in the arena (next parameter /
+        # zero slack), so the product is unchanged and the GEMM can take the large-tile path
+        Kv = d2.stride(0) if (d2.stride(0) % 64 == 0 and d2.stride(0) - V < 64) else V
+        d_tn = K.gemm(1, d2, W16(dec.weight), R, Hd, Kv, splits=K.splits_nn(R, Hd, Kv))
         d_t = K.layernorm_bwd(d_tn, t, R, Hd, tr.LayerNorm.weight.data, mean, rstd, G(tr.LayerNorm.weight), G(tr.LayerNorm.bias))
         d_tpre = torch.empty((R, Hd), dtype=bf16, device=d_t.device)
         K.scale_mask_rows(d_t, R, Hd, out=d_tpre, colsum=G(tr.dense.bias), gelu_in=t_pre)

@@ -86,9 +86,15 @@ def splits_for(M, N, K, keep=False):
 
 def splits_nn(M, N, K):
     """split-K factor for a forward / input-gradient GEMM whose output is too small to fill the chip while K is long
-    (d_hidden = dlogits . W_dec: K = vocabulary).  128x128 tiles, two resident blocks per CU."""
+    (d_hidden = dlogits . W_dec: K = vocabulary).  256x256 tiles (one block per CU) when M >= 256, N % 256 == 0 and
+    K % 64 == 0, else 128x128 tiles (two blocks per CU)."""
+    if K < 4096 or N % 8:
+        return 1
+    if M >= 256 and N % 256 == 0 and K % 64 == 0:
+        tiles = ((M + 255) // 256) * (N // 256)
+        return int(max(1, min(256 // tiles, K // 1024))) if tiles < 128 else 1
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 256 or K < 4096 or N % 8:
+    if tiles >= 256:
         return 1
     return int(max(1, min(512 // tiles, K // 1024)))
 

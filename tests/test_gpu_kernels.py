@@ -140,6 +140,26 @@ def test_gemm_splitk_bf16_output(layout):
     assert K().splits_nn(1024, 768, 30522) > 1 and K().splits_nn(36096, 768, 3072) == 1
 
 
+def test_gemm_splitk_large_tile_and_vocab_rounding():
+    """d_hidden = dlogits . W_dec with the contraction rounded up to the row stride of the logits buffer (30522 -> 30528):
+    zero padding columns x finite rows past V.  Runs the 256x256 split-K path (workspace + bf16 reduction)."""
+    M, N, V = 512, 768, 30522
+    ld = (V + 7) // 8 * 8
+    assert ld % 64 == 0
+    dl = torch.zeros(M, ld, device="cuda", dtype=torch.bfloat16)
+    dl[:, :V] = rb(M, V, scale=0.05)
+    W = torch.zeros(ld, N, device="cuda", dtype=torch.bfloat16)
+    W[:V] = rb(V, N, seed=1, scale=0.05)
+    W[V:] = 3.0                                           # "next parameter" rows: must not contribute
+    s = K().splits_nn(M, N, ld)
+    assert s > 1
+    out = K().gemm(1, dl, W, M, N, ld, splits=s)
+    ref = dl[:, :V].float() @ W[:V].float()
+    close(out, ref, atol=3e-2, rtol=1e-2, what="vocab contraction, rounded K, large-tile split-K")
+    out1 = K().gemm(1, dl[:, :V], W[:V], M, N, V)
+    close(out1, ref, atol=3e-2, rtol=1e-2, what="vocab contraction, exact K")
+
+
 def test_gemm_ragged_vocab_tail():
     M, V, Kd = 64, 1018, 128                         # V % 8 == 2 like 30522
     ld = (V + 7) // 8 * 8
