@@ -10,7 +10,9 @@ Overlap with the backward: the arena is laid out [text embeddings | fusion encod
 The backward finishes the MLM head and all fusion layers (both the MTM and the VTM pass) BEFORE it enters the video
 encoder, so when the first video-side stage starts its backward (engine.VideoEmbedFn) the reducer is notified and
 all-reduces those finished ranges (about half of the 886 MB) on a side stream while the Swin backward -- ~40 % of
-the backward time -- is still running.  finish() reduces what is left.  The division by world size is folded into
+the backward time -- is still running; each Swin stage's range follows when the backward leaves that stage (stage 2
+holds 57 M of the 88 M video-side parameters and finishes with a quarter of the Swin backward still to run).
+finish() reduces what is left (stage 0, the patch / video embeddings: ~1 % of the arena).  The division by world size is folded into
 the fused AdamW kernel (grad_div).
 """
 import torch
@@ -31,6 +33,7 @@ class ArenaReducer:
         self._done = []          # [lo, hi) ranges already reduced in this step
         self._works = []
         self.early_ranges = self._fusion_ranges(a)
+        self.stage_ranges = self._stage_ranges(a)
         if hasattr(a, "listeners"):
             a.listeners.append(self._on_event)
 
@@ -44,6 +47,19 @@ class ArenaReducer:
             names = [n for n in a.names if n.startswith(pre)]
             if names:
                 out.append(a.span(names))
+        return out
+
+    @staticmethod
+    def _stage_ranges(a):
+        """{s: arena range of enc_img.swin.layers.s.*}: final when the first block of stage s has run its backward (the
+        stage's PatchMerging, which follows the blocks in the forward, is differentiated before them)."""
+        if not hasattr(a, "span") or not hasattr(a, "names"):
+            return {}
+        out = {}
+        for s in range(8):
+            names = [n for n in a.names if n.startswith(f"enc_img.swin.layers.{s}.")]
+            if names:
+                out[s] = a.span(names)
         return out
 
     def buckets(self, lo=0, hi=None):
@@ -66,8 +82,12 @@ class ArenaReducer:
         self._done.extend(ranges)
 
     def _on_event(self, name):
-        if name == "fusion_grads_final" and not self._done and self.early_ranges:
+        if name == "fusion_grads_final" and self.early_ranges and not any(r in self._done for r in self.early_ranges):
             self._reduce(self.early_ranges)
+        elif name.startswith("swin_stage") and name.endswith("_grads_final"):
+            rng = self.stage_ranges.get(int(name[len("swin_stage"):-len("_grads_final")]))
+            if rng is not None and rng not in self._done:
+                self._reduce([rng])
 
     def finish(self):
         """Reduce every range not yet reduced in this step; returns when all reduced gradients are usable on the

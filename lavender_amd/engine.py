@@ -95,6 +95,8 @@ class SwinBlockFn(torch.autograd.Function):
                      residual=x_mid)
         if keep:
             ctx.blk, ctx.att, ctx.rpg = blk, att, rpg
+            ctx.notify = geo.get("notify")               # first block of a stage: its backward completes the stage's gradients
+            ctx.arena = geo.get("arena")
             ctx.keep_attn = float(blk.keep_prob) if dp_attn is not None else 1.0
             ctx.has_dp = dp_attn is not None
             ctx.save_for_backward(x, y1, mean1, rstd1, qkv, ao, lse, x_mid, y2, mean2, rstd2, h_pre, h,
@@ -133,6 +135,8 @@ class SwinBlockFn(torch.autograd.Function):
         d_y1 = K.gemm(1, dqkv, W16(a.qkv.weight), M, C, 3 * C)
         dx = K.layernorm_bwd(d_y1, x, M, C, blk.norm1.weight.data, mean1, rstd1, G(blk.norm1.weight), G(blk.norm1.bias),
                              add_in=d_mid)
+        if ctx.notify and ctx.arena is not None:
+            ctx.arena.notify(ctx.notify)                 # data-parallel reducer: this stage's gradient range is final
         return None, dx, None, None, None, None
 
 

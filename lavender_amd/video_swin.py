@@ -220,9 +220,10 @@ class SwinTransformer3D(nn.Module):
         bi = 0
         for s, layer in enumerate(self.layers):
             window, shift = get_window_size((D, Hc, Wc), layer.window_size, layer.shift_size)
-            for blk in layer.blocks:
+            for i, blk in enumerate(layer.blocks):
                 sh = shift if any(blk.shift_size) else (0, 0, 0)
-                geo = dict(B=B, D=D, H=Hc, W=Wc, window=window, shift=sh, cfg_window=layer.window_size)
+                geo = dict(B=B, D=D, H=Hc, W=Wc, window=window, shift=sh, cfg_window=layer.window_size,
+                           notify=f"swin_stage{s}_grads_final" if i == 0 else None, arena=arena)
                 dpa = droppath[2 * bi] if droppath is not None and blk.drop_prob > 0 else None
                 dpm = droppath[2 * bi + 1] if droppath is not None and blk.drop_prob > 0 else None
                 x = E.SwinBlockFn.apply(anchor, x, blk, geo, dpa, dpm)

@@ -19,9 +19,11 @@ def _worker(rank, world, port, q):
     from lavender_amd.dp import ArenaReducer
     n = 1000 * 64 + 64
     synced = []
-    names = ["enc_txt.a", "trsfr.layer.0.w", "trsfr.layer.1.w", "enc_img.swin.w", "fc_mtm.w", "emb_task"]
-    offs = {"enc_txt.a": 0, "trsfr.layer.0.w": 6400, "trsfr.layer.1.w": 19200, "enc_img.swin.w": 32000, "fc_mtm.w": 51200, "emb_task": 60800}
-    ends = {"enc_txt.a": 6400, "trsfr.layer.0.w": 19200, "trsfr.layer.1.w": 32000, "enc_img.swin.w": 51200, "fc_mtm.w": 60800, "emb_task": n}
+    names = ["enc_txt.a", "trsfr.layer.0.w", "trsfr.layer.1.w", "enc_img.swin.layers.0.w", "enc_img.swin.layers.1.w", "fc_mtm.w", "emb_task"]
+    offs = {"enc_txt.a": 0, "trsfr.layer.0.w": 6400, "trsfr.layer.1.w": 19200, "enc_img.swin.layers.0.w": 32000,
+            "enc_img.swin.layers.1.w": 38400, "fc_mtm.w": 51200, "emb_task": 60800}
+    ends = {"enc_txt.a": 6400, "trsfr.layer.0.w": 19200, "trsfr.layer.1.w": 32000, "enc_img.swin.layers.0.w": 38400,
+            "enc_img.swin.layers.1.w": 51200, "fc_mtm.w": 60800, "emb_task": n}
     arena = types.SimpleNamespace(total=n, master=torch.full((n,), float(rank + 1)), grad=torch.zeros(n), names=names, listeners=[],
                                   span=lambda ns: (min(offs[x] for x in ns), max(ends[x] for x in ns)),
                                   sync_half=lambda: synced.append(1))
@@ -43,6 +45,13 @@ def _worker(rank, world, port, q):
         f("fusion_grads_final")
     mid = arena.grad.clone()
     ok &= bool(torch.allclose(mid[6400:32000], expect[6400:32000], atol=1e-6)) and bool(torch.equal(mid[:6400], local[:6400]))
+    # the backward then leaves Swin stage 1 (its range becomes final), later stage 0 is left to finish()
+    ok &= red.stage_ranges == {0: (32000, 38400), 1: (38400, 51200)}
+    for f in arena.listeners:
+        f("swin_stage1_grads_final")
+        f("swin_stage1_grads_final")                          # a repeated event must not reduce twice
+    mid = arena.grad.clone()
+    ok &= bool(torch.allclose(mid[38400:51200], expect[38400:51200], atol=1e-6)) and bool(torch.equal(mid[32000:38400], local[32000:38400]))
     red.finish()
     ok &= bool(torch.allclose(arena.grad, expect, atol=1e-6))
     ok &= red.world == world

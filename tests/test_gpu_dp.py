@@ -69,7 +69,20 @@ def test_two_ranks_allreduce_and_replica_consistency():
     ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in ps)
+    import queue as _queue
+    import time as _time
+    res, t0 = [], _time.time()
+    while len(res) < len(ps):                                    # fail fast when a rank dies instead of waiting out the timeout
+        try:
+            res.append(q.get(timeout=2))
+        except _queue.Empty:
+            dead = [p.exitcode for p in ps if p.exitcode not in (None, 0)]
+            if dead or _time.time() - t0 > 300:
+                for p in ps:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail(f"data-parallel worker failed (exit codes {[p.exitcode for p in ps]})")
+    res = sorted(res)
     for p in ps:
         p.join(timeout=60)
     (r0, rel0, w0a, w0b), (r1, rel1, w1a, w1b) = res
