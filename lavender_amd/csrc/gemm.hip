@@ -903,7 +903,7 @@ static size_t g_splitk_ws_bytes = 0;
 static float* splitk_workspace(size_t bytes) {
     if (bytes > g_splitk_ws_bytes) {
         if (g_splitk_ws) { (void)hipDeviceSynchronize(); (void)hipFree(g_splitk_ws); g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; }
-        size_t want = bytes < ((size_t)64 << 20) ? ((size_t)64 << 20) : bytes + bytes / 2;
+        size_t want = bytes < ((size_t)256 << 20) ? ((size_t)256 << 20) : bytes + bytes / 2;   // 256 MB up front: no re-allocation (device sync) once the step runs
         if (hipMalloc((void**)&g_splitk_ws, want) != hipSuccess) { (void)hipGetLastError(); g_splitk_ws = nullptr; return nullptr; }
         g_splitk_ws_bytes = want;
     }
