@@ -161,12 +161,12 @@ def stats(t):
     return np.array([t.mean().item(), t.abs().max().item(), t.pow(2).mean().sqrt().item()])
 
 
-def run_model_case(ref, name, swin, bert, B, S=224, with_grads=True):
-    print(f"== {name}: swin={swin} bert={bert} B={B} S={S}")
+def run_model_case(ref, name, swin, bert, B, S=224, with_grads=True, T=5, X=32):
+    print(f"== {name}: swin={swin} bert={bert} B={B} S={S} T={T} X={X}")
     m, keys, args = build_reference(ref, swin, bert, B)
     vocab = BERT_CFGS[bert].get("vocab_size", 30522)
     heads = BERT_CFGS[bert].get("num_attention_heads", 12)
-    batch = make_batch(B, S=S, vocab=vocab)
+    batch = make_batch(B, T=T, S=S, X=X, vocab=vocab)
     torch.manual_seed(88)
     txt_m, ans = R.masking(batch["txt"])
     batch["txt"], batch["ans_mtm"] = txt_m, ans
@@ -227,7 +227,7 @@ def run_model_case(ref, name, swin, bert, B, S=224, with_grads=True):
         out_mtm_argmax=out["out_mtm"].argmax(-1).numpy(),
         out_vtm_lse=torch.logsumexp(out["out_vtm"], -1).detach().numpy(),
         out_mtm_stats=stats(out["out_mtm"]), out_vtm_stats=stats(out["out_vtm"]),
-        loss=np.array([l_mtm.item(), l_vtm.item()]), meta=np.array([swin, bert, str(B), str(S), str(heads)]),
+        loss=np.array([l_mtm.item(), l_vtm.item()]), meta=np.array([swin, bert, str(B), str(S), str(heads), str(T), str(X)]),
         **{f"tap_{k}_sub": sub(v) for k, v in taps.items()},
         **{f"tap_{k}_stats": stats(v) for k, v in taps.items()}, **G)
     np.savez_compressed(f"{HERE}/{name}.npz", **res)

@@ -121,8 +121,17 @@ def run_retrieval(ref):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ref = MG.import_reference()
-    # BASELINE config 4 geometry (384^2 frames, window (8,12,12) -> (5,12,12), N = 720 tokens per window) at micro widths
-    MG.run_model_case(ref, "micro12_s384_b2", "micro12", "micro", 2, S=384)
-    run_task_specific(ref)
-    run_retrieval(ref)
+    only = set(sys.argv[1:])                               # e.g. `make_goldens_variants.py shapes` regenerates one group
+    if not only or "large384" in only:
+        # BASELINE config 4 geometry (384^2 frames, window (8,12,12) -> (5,12,12), N = 720 tokens per window) at micro widths
+        MG.run_model_case(ref, "micro12_s384_b2", "micro12", "micro", 2, S=384)
+    if not only or "shapes" in only:
+        # shapes of the shipped pre-training json (4 frames, 32 + 1 text positions) at batch 1 (no negatives: O = min(B, 4) = 1),
+        # and the frame-count maximum (6) with short, mostly padded captions at an odd batch
+        MG.run_model_case(ref, "micro_b1_t4_x33", "micro", "micro", 1, T=4, X=33)
+        MG.run_model_case(ref, "micro_b3_t6_x20", "micro", "micro", 3, T=6, X=20)
+    if not only or "task_specific" in only:
+        run_task_specific(ref)
+    if not only or "retrieval" in only:
+        run_retrieval(ref)
     print("variant goldens written to", HERE)

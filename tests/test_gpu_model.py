@@ -16,11 +16,16 @@ from tests.helpers import BERT_CFGS, make_batch, sub
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_case(swin, bert, B, S=224):
+def _meta(g):
+    swin, bert, B, S, heads, T, X = (g["meta"].tolist() + ["5", "32"])[:7]
+    return swin, bert, int(B), int(S), int(heads), int(T), int(X)
+
+
+def _oracle_case(swin, bert, B, S=224, T=5, X=32):
     from oracle import lavender_ref as R
     bc = BERT_CFGS[bert]
     P = R.filled_params(swin, hidden=bc["hidden"], layers=bc["layers"], ffn=bc["ffn"], vocab=bc["vocab"])
-    batch = make_batch(B, S=S, vocab=bc["vocab"])
+    batch = make_batch(B, T=T, S=S, X=X, vocab=bc["vocab"])
     torch.manual_seed(88)
     batch["txt"], batch["ans_mtm"] = R.masking(batch["txt"])
     return R, P, batch, bc
@@ -30,15 +35,15 @@ def _to_cuda(batch):
     return {k: v.cuda() for k, v in batch.items()}
 
 
-@pytest.mark.parametrize("case", ["micro_b2", "micro_b5", "micro12_s384_b2"])
+@pytest.mark.parametrize("case", ["micro_b2", "micro_b5", "micro12_s384_b2", "micro_b1_t4_x33", "micro_b3_t6_x20"])
 def test_forward_matches_oracle_and_golden(golden_dir, case):
     """micro12_s384_b2 = BASELINE config 4 geometry: 384^2 frames, (5,12,12) windows of 720 tokens (generic window
-    attention kernels), fusion sequences of 757 tokens."""
+    attention kernels), fusion sequences of 757 tokens.  micro_b1_t4_x33: batch 1 (no VTM negatives), 4 frames, 33 text
+    positions (the shipped json); micro_b3_t6_x20: 6 frames, 20 text positions, odd batch."""
     from tests.helpers import build_filled_model
     g = np.load(os.path.join(golden_dir, case + ".npz"))
-    swin, bert, B, S, heads = g["meta"].tolist()
-    B = int(B)
-    R, P, batch, bc = _oracle_case(swin, bert, B, S=int(S))
+    swin, bert, B, S, heads, T, X = _meta(g)
+    R, P, batch, bc = _oracle_case(swin, bert, B, S=S, T=T, X=X)
     m = build_filled_model(swin, bert, B).eval()
     taps = {}
     with torch.no_grad():
@@ -71,14 +76,13 @@ def test_forward_matches_oracle_and_golden(golden_dir, case):
         np.testing.assert_allclose(a[:, :, cols].numpy(), g[key + "_cols"], atol=3e-2)
 
 
-@pytest.mark.parametrize("case", ["micro_b2", "micro12_s384_b2"])
+@pytest.mark.parametrize("case", ["micro_b2", "micro12_s384_b2", "micro_b1_t4_x33", "micro_b3_t6_x20"])
 def test_loss_and_gradients_match_oracle(golden_dir, case):
     from tests.helpers import build_filled_model
     from lavender_amd.agent import CrossEntropyIgnore
     g = np.load(os.path.join(golden_dir, case + ".npz"))
-    swin, bert, B, S, heads = g["meta"].tolist()
-    B = int(B)
-    R, P, batch, bc = _oracle_case(swin, bert, B, S=int(S))
+    swin, bert, B, S, heads, T, X = _meta(g)
+    R, P, batch, bc = _oracle_case(swin, bert, B, S=S, T=T, X=X)
     for v in P.values():
         v.requires_grad_(True)
     np.random.seed(88)

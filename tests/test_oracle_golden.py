@@ -99,14 +99,14 @@ def test_param_groups_and_state_spec(golden_dir):
 
 def _run_case(golden_dir, name, with_grads):
     g = _load(golden_dir, name)
-    swin, bert, B, S, heads = g["meta"].tolist()
-    B, S, heads = int(B), int(S), int(heads)
+    swin, bert, B, S, heads, T, X = (g["meta"].tolist() + ["5", "32"])[:7]
+    B, S, heads, T, X = int(B), int(S), int(heads), int(T), int(X)
     bc = BERT_CFGS[bert]
     P = R.filled_params(swin, hidden=bc["hidden"], layers=bc["layers"], ffn=bc["ffn"], vocab=bc["vocab"])
     if with_grads:
         for k, v in P.items():
             v.requires_grad_(True)
-    batch = make_batch(B, S=S, vocab=bc["vocab"])
+    batch = make_batch(B, T=T, S=S, X=X, vocab=bc["vocab"])
     torch.manual_seed(88)
     batch["txt"], batch["ans_mtm"] = R.masking(batch["txt"])
     assert (batch["txt"].numpy() == g["txt"]).all() and (batch["ans_mtm"].numpy() == g["ans_mtm"]).all()
@@ -149,6 +149,13 @@ def test_micro_b5_forward(golden_dir):
 
 def test_tiny2l_forward_backward(golden_dir):
     _run_case(golden_dir, "tiny2l_b2", True)
+
+
+@pytest.mark.parametrize("case", ["micro_b1_t4_x33", "micro_b3_t6_x20"])
+def test_odd_shapes_forward_backward(golden_dir, case):
+    """Batch 1 (no VTM negatives) with the shipped json's 4 frames / 33 text positions; 6 frames (the frame-embedding
+    maximum) with 20 text positions at batch 3."""
+    _run_case(golden_dir, case, True)
 
 
 def test_micro12_s384_forward_backward(golden_dir):
