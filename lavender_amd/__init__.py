@@ -11,7 +11,7 @@ from .video_swin import SwinTransformer3D, get_vidswin_model, get_window_size  #
 from .model import EncVideo, EncTxt, LAVENDER_Base  # noqa: F401
 from .pretrain_mlm import LAVENDER_Pretrain_MLM, Agent_Pretrain_MLM, masking  # noqa: F401
 from .pretrain_task_specific import LAVENDER_Pretrain, Agent_Pretrain  # noqa: F401
-from .retrieval_mlm import LAVENDER_Retrieval_MLM, Agent_Retrieval_MLM  # noqa: F401
+from .retrieval_mlm import LAVENDER_Retrieval_MLM, Agent_Retrieval_MLM, LAVENDER_RetrievalMlmEval  # noqa: F401
 from .agent import Agent_Base, WarmupLinearLR, CrossEntropyIgnore  # noqa: F401
 
 VIOLET_Base = LAVENDER_Base

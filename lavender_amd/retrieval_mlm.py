@@ -85,3 +85,39 @@ class Agent_Retrieval_MLM(Agent_Base):
             r = self.step(batch, is_train)
             ret.extend(r) if isinstance(r, list) else ret.append(r)
         return self.reduce_mean(float(np.average(ret)))
+
+
+class LAVENDER_RetrievalMlmEval(LAVENDER_Retrieval_MLM):
+    """Two-phase retrieval inference of the reference (eval_retrieval_mlm.py:10-47): 'feat' encodes every video once
+    (mean over its clips) and every caption once; 'cross' runs the fusion encoder + MLM head on (video, text) pairs
+    of cached features.  Forward only."""
+
+    def forward(self, typ, batch):
+        from . import hip as K
+        if typ == 'feat':
+            img, txt, mask = [batch.get(key) for key in ["img", "txt", "mask"]]
+            _B, _Clips, _T, _C, _H, _W = img.shape
+            feat_img, mask_img, feat_txt, mask_txt = self.go_feat(img.view(-1, _T, _C, _H, _W), txt, mask)
+            Lv, Hd = feat_img.shape[1], feat_img.shape[2]
+            if _Clips > 1:                                # mean over the clips of a video: gather-sum kernel + 1/Clips scale kernel
+                rows = feat_img.reshape(_B * _Clips * Lv, Hd)
+                idx = (torch.arange(_B * Lv).view(_B, 1, Lv) // Lv * (_Clips * Lv) + torch.arange(Lv).view(1, 1, Lv)
+                       + torch.arange(_Clips).view(1, _Clips, 1) * Lv)                      # (B, Clips, Lv) source rows
+                lst = idx.permute(0, 2, 1).reshape(-1).to(torch.int32).to(rows.device)      # per output row: its Clips sources
+                start = (torch.arange(_B * Lv + 1, dtype=torch.int32) * _Clips).to(rows.device)
+                summed = K.gather_sum_rows(rows, start, lst, _B * Lv, Hd)
+                scale = torch.full((1,), 1.0 / _Clips, dtype=torch.float32, device=rows.device)
+                mean = torch.empty_like(summed)
+                K.scale_mask_rows(summed, _B * Lv, Hd, out=mean, row_scale=scale, rows_per_group=_B * Lv)
+                feat_img = mean.view(_B, Lv, Hd)
+            else:
+                feat_img = feat_img.view(_B, Lv, Hd)
+            mask_img = mask_img.view(_B, _Clips, -1)[:, 0, :]
+            txt, mask_txt, feat_txt = self.prepro_txt_inputs(txt, mask_txt, feat_txt, task_name=batch.get("task_name"),
+                                                             prompt=None)
+            return feat_img, mask_img, feat_txt, mask_txt, txt
+        elif typ == 'cross':
+            feat_img, mask_img, feat_txt, mask_txt = [batch.get(key) for key in ["feat_img", "mask_img", "feat_txt", "mask_txt"]]
+            out, _ = self.go_cross(feat_img, mask_img, feat_txt, mask_txt)
+            return self.fc_mtm(out[:, feat_img.shape[1]:]), batch.get("txt")
+        raise ValueError(f"typ must be 'feat' or 'cross', got {typ!r}")

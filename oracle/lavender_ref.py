@@ -414,6 +414,22 @@ def retrieval_forward(P, batch, size, heads, ids=SPECIAL):
     return out, ans
 
 
+def retrieval_eval_feat(P, img, txt, size):
+    """LAVENDER_RetrievalMlmEval.forward('feat'), eval_retrieval_mlm.py:19-37: img (B, Clips, T, C, H, W); the
+    video features are averaged over the clips of a video."""
+    B, Cl = img.shape[0], img.shape[1]
+    f_img, m_img = enc_video(P, img.reshape((-1,) + tuple(img.shape[2:])), size)
+    f_img = f_img.view(B, Cl, f_img.shape[1], f_img.shape[2]).mean(dim=1)
+    m_img = m_img.view(B, Cl, -1)[:, 0, :]
+    return f_img, m_img, enc_txt(P, txt)
+
+
+def retrieval_eval_cross(P, f_img, m_img, f_txt, m_txt, heads):
+    """LAVENDER_RetrievalMlmEval.forward('cross'), eval_retrieval_mlm.py:39-47."""
+    out = go_cross(P, f_img, m_img, f_txt, m_txt, heads)
+    return mlm_head(P, out[:, f_img.shape[1]:])
+
+
 # --------------------------------------------------------------------------
 # optimizer-side host logic
 # --------------------------------------------------------------------------

@@ -118,6 +118,35 @@ def run_retrieval(ref):
     assert d < 2e-5 and bool((a == ans).all())
 
 
+def run_retrieval_eval(ref):
+    """Two-phase retrieval inference (eval_retrieval_mlm.py:10-47): 'feat' with 2 clips per video, then 'cross' on every
+    (caption p, video q) pair in the order of Dataset_Product (p outer, q inner)."""
+    EV = importlib.import_module("eval_retrieval_mlm")
+    B, Cl, swin, bert = 2, 2, "micro", "micro"
+    m, keys = build(ref, EV.LAVENDER_RetrievalMlmEval, swin, bert, B)
+    vocab, heads = BERT_CFGS[bert]["vocab_size"], BERT_CFGS[bert]["num_attention_heads"]
+    b = make_batch(B * Cl, T=4, vocab=vocab, seed=9)
+    img = b["img"].view(B, Cl, 4, 3, 224, 224)
+    txt, mask = b["txt"][:B], b["mask"][:B]
+    m.eval()
+    with torch.no_grad():
+        f_img, m_img, f_txt, m_txt, _ = m('feat', {"img": img, "txt": txt, "mask": mask})
+        pi = torch.tensor([p for p in range(B) for q in range(B)]); qi = torch.tensor([q for p in range(B) for q in range(B)])
+        out, _ = m('cross', {"feat_img": f_img[qi], "mask_img": m_img[qi], "feat_txt": f_txt[pi], "mask_txt": m_txt[pi], "txt": txt[pi]})
+    V = out.shape[-1]
+    cols = torch.cat([torch.tensor([2995, 6270]), torch.randperm(V, generator=torch.Generator().manual_seed(5))[:254]])
+    np.savez_compressed(f"{HERE}/retr_eval_micro.npz", txt=txt.numpy(), f_img_sub=sub(f_img), f_img_stats=stats(f_img),
+                        f_txt_sub=sub(f_txt), out_cols=out[:, :, cols].numpy().astype(np.float32), cols=cols.numpy(),
+                        out_lse=torch.logsumexp(out, -1).numpy(), meta=np.array([swin, bert, str(B), str(Cl), str(heads), "4"]))
+    P = {k.replace("trsfr.enc.", "trsfr."): v.detach() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        of_img, om_img, of_txt = R.retrieval_eval_feat(P, img, txt, swin)
+        o = R.retrieval_eval_cross(P, of_img[qi], om_img[qi], of_txt[pi], mask[pi], heads)
+    d1, d2 = (of_img - f_img).abs().max().item(), (o - out).abs().max().item()
+    print(f"   retrieval eval: oracle vs reference max|d| feat {d1:.2e} logits {d2:.2e}")
+    assert d1 < 2e-5 and d2 < 2e-5
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ref = MG.import_reference()
@@ -134,4 +163,6 @@ if __name__ == "__main__":
         run_task_specific(ref)
     if not only or "retrieval" in only:
         run_retrieval(ref)
+    if not only or "retrieval_eval" in only:
+        run_retrieval_eval(ref)
     print("variant goldens written to", HERE)

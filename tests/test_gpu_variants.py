@@ -222,3 +222,36 @@ def test_retrieval_agent_step_and_eval():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 1.0
     ac = ag.step(batch, False)
     assert isinstance(ac, list) and len(ac) == B and set(ac) <= {0.0, 1.0}
+
+
+def test_retrieval_eval_two_phase_matches_oracle_and_golden(golden_dir):
+    """LAVENDER_RetrievalMlmEval 'feat' (2 clips per video, mean on the GPU) and 'cross' (every caption x video pair)."""
+    from oracle import lavender_ref as R
+    from tests.helpers import build_filled_model
+    from lavender_amd import LAVENDER_RetrievalMlmEval
+    g = np.load(os.path.join(golden_dir, "retr_eval_micro.npz"))
+    swin, bert, B, Cl, heads, T = g["meta"].tolist()
+    B, Cl, heads, T = int(B), int(Cl), int(heads), int(T)
+    bc = BERT_CFGS[bert]
+    P = R.filled_params(swin, hidden=bc["hidden"], layers=bc["layers"], ffn=bc["ffn"], vocab=bc["vocab"])
+    b = make_batch(B * Cl, T=T, vocab=bc["vocab"], seed=9)
+    img = b["img"].view(B, Cl, T, 3, 224, 224)
+    txt, mask = b["txt"][:B], b["mask"][:B]
+    pi = torch.tensor([p for p in range(B) for q in range(B)]); qi = torch.tensor([q for p in range(B) for q in range(B)])
+    with torch.no_grad():
+        rf_img, rm_img, rf_txt = R.retrieval_eval_feat(P, img, txt, swin)
+        ref = R.retrieval_eval_cross(P, rf_img[qi], rm_img[qi], rf_txt[pi], mask[pi], heads)
+    m = build_filled_model(swin, bert, B, cls=LAVENDER_RetrievalMlmEval).eval()
+    with torch.no_grad():
+        f_img, m_img, f_txt, m_txt, t = m('feat', {"img": img.cuda(), "txt": txt.cuda(), "mask": mask.cuda()})
+        assert f_img.shape == (B, rf_img.shape[1], bc["hidden"]) and (m_img.cpu() == rm_img).all() and (t.cpu() == txt).all()
+        d = (f_img.float().cpu() - rf_img).abs()
+        assert d.max() < 0.1 and d.mean() < 1e-2, (d.max().item(), d.mean().item())
+        out, _ = m('cross', {"feat_img": f_img[qi.cuda()], "mask_img": m_img[qi.cuda()], "feat_txt": f_txt[pi.cuda()],
+                             "mask_txt": m_txt[pi.cuda()], "txt": txt[pi].cuda()})
+    a = out.float().cpu()
+    d = (a - ref).abs()
+    print("retrieval eval logits max", d.max().item(), "mean", d.mean().item())
+    assert d.max() < 3e-2 and d.mean() < 5e-3
+    np.testing.assert_allclose(a[:, :, torch.from_numpy(g["cols"])].numpy(), g["out_cols"], atol=3e-2)
+    assert np.abs(torch.logsumexp(a, -1).numpy() - g["out_lse"]).max() < 2e-2

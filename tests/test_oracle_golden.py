@@ -240,3 +240,24 @@ def test_retrieval_variant(golden_dir):
     ls.backward()
     P["emb_task"].grad = None
     _check_grads(P, g)
+
+
+def test_retrieval_eval_two_phase(golden_dir):
+    """LAVENDER_RetrievalMlmEval (eval_retrieval_mlm.py:10-47): clip-averaged video features, then all (caption, video) pairs."""
+    g = _load(golden_dir, "retr_eval_micro")
+    swin, bert, B, Cl, heads, T = g["meta"].tolist()
+    B, Cl, heads, T = int(B), int(Cl), int(heads), int(T)
+    bc = BERT_CFGS[bert]
+    P = R.filled_params(swin, hidden=bc["hidden"], layers=bc["layers"], ffn=bc["ffn"], vocab=bc["vocab"])
+    b = make_batch(B * Cl, T=T, vocab=bc["vocab"], seed=9)
+    img = b["img"].view(B, Cl, T, 3, 224, 224)
+    txt, mask = b["txt"][:B], b["mask"][:B]
+    assert (txt.numpy() == g["txt"]).all()
+    with torch.no_grad():
+        f_img, m_img, f_txt = R.retrieval_eval_feat(P, img, txt, swin)
+        pi = torch.tensor([p for p in range(B) for q in range(B)]); qi = torch.tensor([q for p in range(B) for q in range(B)])
+        out = R.retrieval_eval_cross(P, f_img[qi], m_img[qi], f_txt[pi], mask[pi], heads)
+    np.testing.assert_allclose(sub(f_img), g["f_img_sub"], atol=1e-5)
+    np.testing.assert_allclose(sub(f_txt), g["f_txt_sub"], atol=1e-5)
+    np.testing.assert_allclose(out[:, :, torch.from_numpy(g["cols"])].numpy(), g["out_cols"], atol=1e-5)
+    np.testing.assert_allclose(torch.logsumexp(out, -1).numpy(), g["out_lse"], atol=1e-5)
