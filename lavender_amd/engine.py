@@ -300,6 +300,28 @@ class PairSeqFn(torch.autograd.Function):
         return d[:B * Lv].view(B, Lv, Hd), d[B * Lv:].view(B, X, Hd), None, None
 
 
+class RowGatherFn(torch.autograd.Function):
+    """rows[idx] of a (R, C) tensor with distinct indices (the supervised positions of the loss-aware MLM head); the
+    backward is the same gather kernel over the inverse map (unselected rows read as zero)."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        R, C = src.shape
+        idx = np.asarray(idx, dtype=np.int32)
+        out = K.gather_rows(src, torch.from_numpy(idx).to(src.device, non_blocking=True), len(idx), C)
+        if ctx.needs_input_grad[0]:
+            inv = np.full(R, -1, dtype=np.int32)
+            inv[idx] = np.arange(len(idx), dtype=np.int32)
+            ctx.inv = torch.from_numpy(inv).to(src.device, non_blocking=True)
+            ctx.shape = (R, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        R, C = ctx.shape
+        return K.gather_rows(dy.contiguous(), ctx.inv, R, C), None
+
+
 # ---------------------------------------------------------------------------------------------------
 # fusion encoder layer / MLM head / loss
 # ---------------------------------------------------------------------------------------------------

@@ -255,3 +255,44 @@ def test_retrieval_eval_two_phase_matches_oracle_and_golden(golden_dir):
     assert d.max() < 3e-2 and d.mean() < 5e-3
     np.testing.assert_allclose(a[:, :, torch.from_numpy(g["cols"])].numpy(), g["out_cols"], atol=3e-2)
     assert np.abs(torch.logsumexp(a, -1).numpy() - g["out_lse"]).max() < 2e-2
+
+
+def test_loss_aware_head_same_loss_and_gradients():
+    """args.loss_aware_head (opt-in): MLM head + cross-entropy on the supervised positions only must give
+    the same losses and parameter gradients as the reference-shaped full-logit path (same dropout seeds)."""
+    from tests.helpers import Tok, make_args
+    import lavender_amd as LA
+    from lavender_amd import hip as K
+    from lavender_amd.dist import set_seed
+    B = 4
+    res = []
+    for aware in (False, True):
+        set_seed(88)
+        args = make_args("micro", "micro", B, lr=1e-3, max_iter=40, loss_aware_head=aware)
+        m = LA.LAVENDER_Pretrain_MLM(args, Tok()).cuda()
+        m.arena()
+        ag = LA.Agent_Pretrain_MLM(args, m)
+        b = make_batch(B, vocab=BERT_CFGS["micro"]["vocab"])
+        torch.manual_seed(5)
+        b.update(ag.masking(b["txt"], b["mask"]))
+        batch = ag.prepare_batch(b)
+        K.reseed(1234)
+        np.random.seed(7)
+        m.train()
+        m.arena().zero_grad()
+        out = m(batch)
+        if aware:
+            assert out["out_mtm"].dim() == 2 and out["out_mtm"].shape[0] == batch["_n_mtm"] and out["out_vtm"].shape[0] == B * 4
+        else:
+            assert out["out_mtm"].shape[:2] == (B, 32)
+        ls_mtm = ag.loss_func(out["out_mtm"].flatten(0, out["out_mtm"].dim() - 2), out["ans_mtm"].flatten(), batch["_n_mtm"])
+        ls_vtm = ag.loss_func(out["out_vtm"].flatten(0, out["out_vtm"].dim() - 2), out["ans_vtm"].flatten(), B * 4)
+        (ls_mtm + ls_vtm).backward()
+        torch.cuda.synchronize()
+        res.append((ls_mtm.item(), ls_vtm.item(), m.arena().grad.clone()))
+    (a1, a2, ga), (b1, b2, gb) = res
+    print("full", a1, a2, "aware", b1, b2)
+    assert abs(a1 - b1) < 2e-3 and abs(a2 - b2) < 2e-3
+    rel = ((ga - gb).norm() / ga.norm()).item()
+    print("gradient arena rel diff", rel)
+    assert rel < 1e-2
