@@ -1,0 +1,69 @@
+"""CPU experiment (no GPU): where the bf16 error of the full-width model comes from.  The oracle is re-run with bf16
+rounding injected (a) on the residual stream only, (b) on weights + GEMM operands + branch intermediates only, (c) both,
+and the MLM logits are compared with the fp32 oracle (Swin-B + 12 layers, batch 1).
+   python tools/bf16_error_budget.py"""
+import sys, time
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, torch.nn.functional as F
+from oracle import lavender_ref as R
+from tests.helpers import make_batch, BERT_CFGS
+torch.set_num_threads(8)
+bf = lambda t: t.bfloat16().float()
+ident = lambda t: t
+RS, RB = ident, ident
+
+def swin_block(P, pre, x, heads, cfg_window, cfg_shift, dp=None):
+    B, D, H, W, C = x.shape
+    window, shift = R.use_window((D, H, W), cfg_window, cfg_shift)
+    h = RB(R._ln(x, P, pre + ".norm1", 1e-5))
+    mask = None
+    if any(shift):
+        h = torch.roll(h, (-shift[0], -shift[1], -shift[2]), (1, 2, 3))
+        mask = R.shift_mask(D, H, W, window, shift)
+    xw = R.partition(h, window)
+    Bw, N, Cc = xw.shape; hd = Cc // heads
+    qkv = RB(R._lin(xw, P, pre + ".attn.qkv")).reshape(Bw, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+    att = q @ k.transpose(-2, -1)
+    idx = R.rel_pos_index(cfg_window)[:N, :N].reshape(-1)
+    bias = P[pre + ".attn.relative_position_bias_table"][idx].reshape(N, N, heads).permute(2, 0, 1)
+    att = att + bias[None]
+    if mask is not None:
+        nW = mask.shape[0]
+        att = (att.reshape(Bw // nW, nW, heads, N, N) + mask[None, :, None]).reshape(-1, heads, N, N)
+    out = RB((att.softmax(-1) @ v).transpose(1, 2).reshape(Bw, N, Cc))
+    a = R._lin(out, P, pre + ".attn.proj")
+    h = R.unpartition(a, window, B, D, H, W)
+    if any(shift):
+        h = torch.roll(h, shift, (1, 2, 3))
+    x = RS(x + h)
+    hh = RB(F.gelu(R._lin(RB(R._ln(x, P, pre + ".norm2", 1e-5)), P, pre + ".mlp.fc1")))
+    return RS(x + R._lin(hh, P, pre + ".mlp.fc2"))
+
+def bert_layer(P, pre, x, add_mask, heads):
+    B, L, Hd = x.shape; hd = Hd // heads
+    split = lambda t: t.reshape(B, L, heads, hd).transpose(1, 2)
+    xo = RB(x); q = split(RB(R._lin(xo, P, pre + ".attention.self.query"))); k = split(RB(R._lin(xo, P, pre + ".attention.self.key"))); v = split(RB(R._lin(xo, P, pre + ".attention.self.value")))
+    s = q @ k.transpose(-1, -2) * hd ** -0.5 + add_mask
+    ctx = RB((s.softmax(-1) @ v).transpose(1, 2).reshape(B, L, Hd))
+    x = RS(R._ln(RS(R._lin(ctx, P, pre + ".attention.output.dense") + x), P, pre + ".attention.output.LayerNorm", 1e-12))
+    h = R._lin(RB(F.gelu(R._lin(RB(x), P, pre + ".intermediate.dense"))), P, pre + ".output.dense")
+    return RS(R._ln(RS(h + x), P, pre + ".output.LayerNorm", 1e-12))
+
+R.swin_block = swin_block; R.bert_layer = bert_layer
+bc = BERT_CFGS["b12l"]
+P = R.filled_params("base", hidden=bc["hidden"], layers=bc["layers"], ffn=bc["ffn"], vocab=bc["vocab"])
+P = {k: (v.bfloat16().float() if (v.dim() >= 2 and "emb" not in k and "table" not in k) else v) for k, v in P.items()}
+P32 = R.filled_params("base", hidden=bc["hidden"], layers=bc["layers"], ffn=bc["ffn"], vocab=bc["vocab"])
+batch = make_batch(1, vocab=bc["vocab"])
+torch.manual_seed(88); batch["txt"], batch["ans_mtm"] = R.masking(batch["txt"])
+res = {}
+for name, rs, rb in (("fp32", ident, ident), ("stream only", bf, ident), ("branch only", ident, bf), ("both", bf, bf)):
+    RS, RB = rs, rb
+    with torch.no_grad():
+        np.random.seed(88); o = R.pretrain_forward(P32 if name == "fp32" else P, batch, "base", 12)
+    res[name] = o["out_mtm"]
+    if name != "fp32":
+        d = (o["out_mtm"] - res["fp32"]).abs()
+        print(f"{name:12s}: logits max|d| {d.max().item():.2e} mean {d.mean().item():.2e}")
