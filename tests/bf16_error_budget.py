@@ -1,7 +1,7 @@
 """CPU experiment (no GPU): where the bf16 error of the full-width model comes from.  The oracle is re-run with bf16
 rounding injected (a) on the residual stream only, (b) on weights + GEMM operands + branch intermediates only, (c) both,
 and the MLM logits are compared with the fp32 oracle (Swin-B + 12 layers, batch 1).
-   python tools/bf16_error_budget.py"""
+   python tests/bf16_error_budget.py"""
 import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
