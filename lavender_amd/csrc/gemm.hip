@@ -145,8 +145,12 @@ __device__ __forceinline__ bf16x8 frag_read(const char* lds, int t16, int ks, in
 enum : unsigned { EF_BIAS = 1, EF_ACT = 2, EF_GIN = 4, EF_DROP = 8, EF_RSCALE = 16, EF_RES = 32, EF_COLSUM = 64,
                   EF_TNFLUSH = 0x4000, EF_GENERIC = 0x8000, EF_ALL = 0xFFFF };
 
-template <int ROWS, int NTHR, unsigned F = EF_ALL>
+// CH = 16-byte chunks per staged row (16: a 128-column block-wide tile; 8: a 64-column tile private to ONE wave -- then
+// NTHR == 64, `cl` is that wave's LDS slice with row stride CSTR and nothing here synchronises the block).
+template <int ROWS, int NTHR, unsigned F = EF_ALL, int CH = 16, int CSTR = CSTRIDE>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int m0, int n0, int split = 0) {
+    constexpr bool WAVE = CH != 16;
+    constexpr int RPP = NTHR / CH;                          // rows per pass
     const lav_gemm_epilogue& e = g.e;
     if constexpr (F == EF_TNFLUSH) {
         // weight-gradient flush only: alpha * acc -> split-K workspace tile | owned read-modify-write | fp32 atomics
@@ -186,8 +190,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
     const bool has_rscale = (F & EF_RSCALE) && e.row_scale;
     const bool has_res = (F & EF_RES) && e.residual;
     const bool has_colsum = (F & EF_COLSUM) && e.colsum;
-    const int etid = threadIdx.x;
-    const int cc = etid & 15;
+    const int etid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
+    const int cc = etid % CH;
     const int gcol = n0 + cc * 8;
     float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -201,7 +205,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
     // "outside" test every access is a full 16-byte one (compile-time) -- the preloads below run BEFORE that test
     const bool full = GEN ? ncols == 8 : true;
     const bool inside = GEN ? ncols == 8 : ncols > 0;
-    constexpr int NIT = ROWS / (NTHR / 16);
+    constexpr int NIT = ROWS / RPP;
     constexpr int GRP = 4;                                 // rows handled together: their gelu_in / residual loads are
     static_assert(NIT % GRP == 0, "epilogue row grouping");  // issued back-to-back so HBM latency is paid once per group
 #pragma unroll 1
@@ -209,7 +213,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         uint4 pre_g[GRP], pre_r[GRP];
 #pragma unroll
         for (int u = 0; u < GRP; ++u) {
-            const int grow = m0 + (etid >> 4) + (NTHR / 16) * (j0 + u);
+            const int grow = m0 + etid / CH + RPP * (j0 + u);
             pre_g[u] = make_uint4(0, 0, 0, 0); pre_r[u] = pre_g[u];
             if (inside && grow < g.M) {
                 if (has_gin) pre_g[u] = *(const uint4*)((const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol);
@@ -219,12 +223,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
 #pragma unroll
       for (int u = 0; u < GRP; ++u) {
         const int j = j0 + u;
-        const int row = (etid >> 4) + (NTHR / 16) * j;
+        const int row = etid / CH + RPP * j;
         const int grow = m0 + row;
         if (grow >= g.M || ncols <= 0) continue;
         float v[8];
-        *(float4*)&v[0] = *(const float4*)&cl[row * CSTRIDE + cc * 8];
-        *(float4*)&v[4] = *(const float4*)&cl[row * CSTRIDE + cc * 8 + 4];
+        *(float4*)&v[0] = *(const float4*)&cl[row * CSTR + cc * 8];
+        *(float4*)&v[4] = *(const float4*)&cl[row * CSTR + cc * 8 + 4];
 #pragma unroll
         for (int x = 0; x < 8; ++x) v[x] = v[x] * e.alpha + bias[x];
         if (GEN && e.preact && !e.preact_is_grad) {
@@ -327,15 +331,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
       }
     }
     if (has_colsum) {
-        __syncthreads();
-        float* red = cl;                                  // [NTHR/16][128]
+        constexpr int W = CH * 8;                           // staged tile width in columns
+        if (WAVE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); else __syncthreads();
+        float* red = cl;                                  // [RPP][W]
 #pragma unroll
-        for (int x = 0; x < 8; ++x) red[(etid >> 4) * 128 + cc * 8 + x] = csum[x];
-        __syncthreads();
-        if (etid < 128 && n0 + etid < g.N) {
+        for (int x = 0; x < 8; ++x) red[(etid / CH) * W + cc * 8 + x] = csum[x];
+        if (WAVE) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } else __syncthreads();
+        if (etid < W && n0 + etid < g.N) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < NTHR / 16; ++r) s += red[r * 128 + etid];
+            for (int r = 0; r < RPP; ++r) s += red[r * W + etid];
             atomicAdd(e.colsum + n0 + etid, s);
         }
     }
@@ -687,6 +692,23 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
             }
     }
 
+    if constexpr (F != EF_ALL && F != EF_TNFLUSH) {
+        // specialised epilogues: each wave stages and stores its own 64 x 64 block through a private LDS slice (see the
+        // 256x256 kernel) -- all operand stages were consumed before the loop's last barrier
+        constexpr int WS = 68;
+        float* clw = (float*)smem + wave * (64 * WS);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    clw[(i * 16 + (lane >> 4) * 4 + r) * WS + j * 16 + (lane & 15)] = acc[i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        gemm_epilogue<64, 64, F, 8, WS>(g, clw, m0 + wm * 64, n0 + wn * 64, split);
+        return;
+    }
     float* cl = (float*)smem;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -710,7 +732,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
 // already covers the load latency.  The accumulator tile is handed to the epilogue in two 128-column halves.
 // ------------------------------------------------------------------------------------------------------
 #define HUGE_STAGE 65536
-#define HUGE_LDS (BIG_BM * CSTRIDE * 4 > 2 * HUGE_STAGE ? BIG_BM * CSTRIDE * 4 : 2 * HUGE_STAGE)
+#define HUGE_LDS 139264   // max(2 stages of 64 KB, block-wide epilogue 256 x 132 floats, eight wave-private 64 x 68 float slices)
 
 // NW = waves per block.  8: 2 x 4 waves of 128x64 (shipped).  Per k-tile the LDS pipe moves 192 KB of fragment reads +
 // 64 KB of direct-to-LDS writes = 2048 clk, exactly the MFMA time -- the k-loop sits near 47 % of the MFMA peak.
@@ -814,6 +836,29 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
             }
     }
 
+    if constexpr (NW == 8 && F != EF_ALL && F != EF_TNFLUSH) {
+        // specialised forward / input-gradient epilogues: every wave stages its own 128 x 64 accumulator block through a
+        // private LDS slice in two 64-row halves and stores it -- no block barriers, no waves idling while the other half
+        // of the tile is staged (the block-wide version below costs ~5.5 us per tile)
+        constexpr int WS = 68;                            // private row stride (floats)
+        float* clw = (float*)smem + wave * (64 * WS);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                     // unrolled: acc[] must be indexed with compile-time constants
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        clw[(i * 16 + (lane >> 4) * 4 + r) * WS + j * 16 + (lane & 15)] = acc[h * 4 + i][j][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the slice is only read by this wave
+            __builtin_amdgcn_wave_barrier();
+            gemm_epilogue<64, 64, F, 8, WS>(g, clw, m0 + wm * 128 + h * 64, n0 + wn * 64, split);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     float* cl = (float*)smem;
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
