@@ -241,12 +241,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
                 // GELU and GELU' share erf and exp: y = z Phi(z), y' = Phi(z) + z phi(z); y' is what the backward needs
                 float gp[8];
 #pragma unroll
-                for (int x = 0; x < 8; ++x) {
-                    const float z = v[x];
-                    const float cdf = 0.5f * (1.0f + fast_erf(z * 0.70710678118654752f));
-                    gp[x] = cdf + z * 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * z * z);
-                    v[x] = z * cdf;
-                }
+                for (int x = 0; x < 8; ++x) gelu_and_grad(v[x], v[x], gp[x]);
                 bf16_t* p = (bf16_t*)e.preact + (long)grow * e.ldp + gcol;
                 if (full) *(uint4*)p = pack8(gp);
                 else for (int x = 0; x < ncols; ++x) p[x] = f2bf(gp[x]);
