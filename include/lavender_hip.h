@@ -241,6 +241,17 @@ int lav_adamw_step(void* stream, long n, float* p, const float* g, float* m, flo
                    const uint8_t* block_group /* group id (0..3) per 64-element block of the arena */,
                    const float lr[4], const float wd[4], float beta1, float beta2, float eps, int step,
                    const float* gradsq, float max_norm, float grad_div);
+/* Transposed bf16 working copy of the weight matrices: every nn.Linear backward-to-input (dx = dy W, the autograd of
+ * video_swin.py:73-79,137-139 / the HF BERT linears) then runs in the forward GEMM layout.  One launch over all
+ * matrices: dst[dst_off + c * ld_dst + r] = src[src_off + r * cols + c]; tile0 = index of the matrix's first 64x64
+ * tile in the launch (exclusive prefix sum of ceil(rows/64) * ceil(cols/64)); src_off / dst_off in elements, 8-aligned,
+ * ld_dst % 8 == 0. */
+typedef struct lav_mat_desc {
+    long src_off, dst_off;
+    int rows, cols, ld_dst, tile0;
+} lav_mat_desc;
+int lav_transpose_bf16_batched(void* stream, int n_mats, const lav_mat_desc* descs_dev, int total_tiles, const void* src_bf16,
+                               void* dst_bf16);
 int lav_cast_f32_to_bf16(void* stream, long n, const float* in, void* out);
 int lav_fill_droppath(void* stream, int n_blocks, int B, const float* keep_prob, uint32_t seed, float* scale);
 

@@ -72,6 +72,7 @@ _SIGS = {
     "lav_cross_entropy_fwd_bwd": (i32, [vp, i32, i32, vp, i64, vp, vp, f32, i32]),
     "lav_scale_by_count": (i32, [vp, i64, vp, vp, f32]),
     "lav_cross_entropy_f32_fwd_bwd": (i32, [vp, i32, i32, vp, i64, vp, vp, f32, i32]),
+    "lav_transpose_bf16_batched": (i32, [vp, i32, vp, i32, vp, vp]),
     "lav_pair_score_fwd": (i32, [vp, i32, i32, vp, i64, vp, vp, f32, i32, vp, i64]),
     "lav_pair_score_bwd": (i32, [vp, i32, i32, vp, i64, i32, f32, vp, i64, vp, i64, vp, vp, i64, vp, vp]),
     "lav_sumsq_f32": (i32, [vp, i64, vp, vp]),
@@ -79,6 +80,11 @@ _SIGS = {
     "lav_cast_f32_to_bf16": (i32, [vp, i64, vp, vp]),
     "lav_fill_droppath": (i32, [vp, i32, i32, vp, u32, vp]),
 }
+class MatDesc(C.Structure):                  # struct lav_mat_desc
+    _fields_ = [("src_off", C.c_long), ("dst_off", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("ld_dst", C.c_int),
+                ("tile0", C.c_int)]
+
+
 EXPORTS = tuple(_SIGS)
 
 for _name, (_res, _args) in _SIGS.items():

@@ -81,6 +81,7 @@ class ParamArena:
             grp[o // ALIGN:(o + k + ALIGN - 1) // ALIGN] = param_group_of(n)
             self.params[n] = p
         self.block_group = grp.to(self.device)
+        self._build_transposed(named)
         self.m = None
         self.v = None
         self.gradsq = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -89,10 +90,50 @@ class ParamArena:
         self.stale = True
         self.sync_half()
 
+    # -- transposed bf16 copy of the weight matrices ---------------------------------------------------
+    def _build_transposed(self, named):
+        """W^T next to W for every nn.Linear-style weight (2-D, not an embedding / bias table): the input-gradient GEMMs
+        dx = dy W then read a K-contiguous operand like the forward ones.  q/k/v of one attention form ONE (3H, H)
+        matrix (they are adjacent in the arena), so its transpose is the (H, 3H) operand of the fused backward GEMM."""
+        import ctypes as C
+        import numpy as np
+        from ._lib import MatDesc
+        mats, off_t, tile0 = [], 0, 0
+        skip = ("embeddings", "relative_position_bias_table", "emb_", ".key.weight", ".value.weight")
+        for n, p in named:
+            if p.dim() != 2 or not n.endswith("weight") or any(k in n for k in skip) or p.shape[0] < 8 or p.shape[1] % 8:
+                continue
+            rows, cols = p.shape
+            if _QKV.match(n):
+                rows *= 3                                       # query.weight heads the fused (3H, H) block
+            ld = (rows + 63) // 64 * 64
+            mats.append((n, self.offsets[n], off_t, rows, cols, ld, tile0))
+            tile0 += ((rows + 63) // 64) * ((cols + 63) // 64)
+            off_t += (cols * ld + ALIGN - 1) // ALIGN * ALIGN
+        self.half_t = torch.zeros(max(off_t, ALIGN), dtype=torch.bfloat16, device=self.device)
+        self._t_tiles = tile0
+        self._t_views = {}
+        arr = (MatDesc * max(len(mats), 1))()
+        for i, (n, so, do, rows, cols, ld, t0) in enumerate(mats):
+            arr[i] = MatDesc(so, do, rows, cols, ld, t0)
+            self._t_views[n] = self.half_t[do:do + cols * ld].view(cols, ld)
+        self._t_n = len(mats)
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self._t_desc = torch.from_numpy(raw).to(self.device)
+        for n, p in named:
+            if n in self._t_views:
+                rows = p.shape[0] * (3 if _QKV.match(n) else 1)
+                p._lav16t = self._t_views[n][:, :rows]
+
+    def sync_transposed(self):
+        if self._t_n:
+            K.transpose_batched(self._t_n, self._t_desc, self._t_tiles, self.half_full, self.half_t)
+
     # -- bf16 working copy -------------------------------------------------------------------------
     def sync_half(self):
-        """Refresh the bf16 working copy from the fp32 master (after load_state_dict / a foreign optimizer)."""
+        """Refresh the bf16 working copies from the fp32 master (after load_state_dict / a foreign optimizer)."""
         K.cast_bf16(self.master, self.half, self.total)
+        self.sync_transposed()
         self.stale = False
 
     def sync_half_if_stale(self):
@@ -137,3 +178,4 @@ class ParamArena:
             K.sumsq(self.grad, self.total, self.gradsq)
         K.adamw(self.total, self.master, self.grad, self.m, self.v, self.half, self.block_group, lr4, wd4, betas[0], betas[1],
                 eps, step, self.gradsq if max_norm > 0 else None, max_norm, grad_div)
+        self.sync_transposed()

@@ -24,6 +24,14 @@ def W16(p):
         raise RuntimeError("parameter is not in a ParamArena: call model.cuda() / model.build_arena() first") from None
 
 
+def W16T(p):
+    """transposed bf16 working copy (in_features, out_features): the K-contiguous operand of dx = dy W"""
+    try:
+        return p._lav16t
+    except AttributeError:
+        raise RuntimeError("parameter has no transposed working copy in the ParamArena") from None
+
+
 def G(p):
     return p._lavg
 
@@ -117,22 +125,22 @@ class SwinBlockFn(torch.autograd.Function):
         # --- MLP branch: out = x_mid + s * fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------
         K.gemm(2, dy, h, C, 4 * C, M, out=G(mlp.fc2.weight), accumulate=True, k_keep=dp_mlp, k_rows_per_group=rpg,
                alpha=alpha if dp_mlp is not None else 1.0, splits=K.splits_for(C, 4 * C, M, dp_mlp is not None), rowsum_a=G(mlp.fc2.bias))
-        dh = K.gemm(1, dy, W16(mlp.fc2.weight), M, 4 * C, C, gelu_in=h_pre, gelu_in_is_grad=True, row_scale=dp_mlp,
+        dh = K.gemm(0, dy, W16T(mlp.fc2.weight), M, 4 * C, C, gelu_in=h_pre, gelu_in_is_grad=True, row_scale=dp_mlp,
                     rows_per_group=rpg, colsum=G(mlp.fc1.bias))
         K.gemm(2, dh, y2, 4 * C, C, M, out=G(mlp.fc1.weight), accumulate=True, splits=K.splits_for(4 * C, C, M))
-        d_y2 = K.gemm(1, dh, W16(mlp.fc1.weight), M, C, 4 * C)
+        d_y2 = K.gemm(0, dh, W16T(mlp.fc1.weight), M, C, 4 * C)
         del dh
         d_mid = K.layernorm_bwd(d_y2, x_mid, M, C, blk.norm2.weight.data, mean2, rstd2, G(blk.norm2.weight), G(blk.norm2.bias),
                                 add_in=dy)
         # --- attention branch: x_mid = x + s * proj(attn(qkv(LN1(x)))) ---------------------------------
         K.gemm(2, d_mid, ao, C, C, M, out=G(a.proj.weight), accumulate=True, k_keep=dp_attn, k_rows_per_group=rpg,
                alpha=alpha if dp_attn is not None else 1.0, splits=K.splits_for(C, C, M, dp_attn is not None), rowsum_a=G(a.proj.bias))
-        d_ao = K.gemm(1, d_mid, W16(a.proj.weight), M, C, C, row_scale=dp_attn, rows_per_group=rpg)
+        d_ao = K.gemm(0, d_mid, W16T(a.proj.weight), M, C, C, row_scale=dp_attn, rows_per_group=rpg)
         dqkv = torch.empty_like(qkv)
         att.bwd(qkv, ao, d_ao, lse, dqkv, G(a.relative_position_bias_table))
         K.gemm(2, dqkv, y1, 3 * C, C, M, out=G(a.qkv.weight), accumulate=True, splits=K.splits_for(3 * C, C, M),
                rowsum_a=G(a.qkv.bias))
-        d_y1 = K.gemm(1, dqkv, W16(a.qkv.weight), M, C, 3 * C)
+        d_y1 = K.gemm(0, dqkv, W16T(a.qkv.weight), M, C, 3 * C)
         dx = K.layernorm_bwd(d_y1, x, M, C, blk.norm1.weight.data, mean1, rstd1, G(blk.norm1.weight), G(blk.norm1.bias),
                              add_in=d_mid)
         if ctx.notify and ctx.arena is not None:
@@ -163,7 +171,7 @@ class PatchMergeFn(torch.autograd.Function):
         rows = y.shape[0]
         dout = dout.contiguous()
         K.gemm(2, dout, y, 2 * C, 4 * C, rows, out=G(mod.reduction.weight), accumulate=True, splits=K.splits_for(2 * C, 4 * C, rows))
-        d_y = K.gemm(1, dout, W16(mod.reduction.weight), rows, 4 * C, 2 * C)
+        d_y = K.gemm(0, dout, W16T(mod.reduction.weight), rows, 4 * C, 2 * C)
         dx = K.layernorm_bwd(d_y, x, rows, 4 * C, mod.norm.weight.data, mean, rstd, G(mod.norm.weight), G(mod.norm.bias),
                              gather=(H, W, C))
         return None, dx, None, None, None, None
@@ -232,7 +240,7 @@ class VideoEmbedFn(torch.autograd.Function):
             return None, dfeat, None, None, None, None
         K.gemm(2, dfeat, tok, Hd, Cl, M, out=G(enc.fc.weight), accumulate=True, splits=K.splits_for(Hd, Cl, M),
                rowsum_a=G(enc.fc.bias))
-        dtok = K.gemm(1, dfeat, W16(enc.fc.weight), M, Cl, Hd)
+        dtok = K.gemm(0, dfeat, W16T(enc.fc.weight), M, Cl, Hd)
         return None, dtok, None, None, None, None
 
 
@@ -375,20 +383,20 @@ class BertLayerFn(torch.autograd.Function):
         d_pre2 = K.layernorm_bwd(dy, pre2, R, Hd, outp.LayerNorm.weight.data, mean2, rstd2, G(outp.LayerNorm.weight),
                                  G(outp.LayerNorm.bias), dx2=d_dense2, dropout_p=p, seed=s2, colsum=G(outp.dense.bias))
         K.gemm(2, d_dense2, h, Hd, F, R, out=G(outp.dense.weight), accumulate=True, splits=K.splits_for(Hd, F, R))
-        dh = K.gemm(1, d_dense2, W16(outp.dense.weight), R, F, Hd, gelu_in=h_pre, gelu_in_is_grad=True, colsum=G(inter.dense.bias))
+        dh = K.gemm(0, d_dense2, W16T(outp.dense.weight), R, F, Hd, gelu_in=h_pre, gelu_in_is_grad=True, colsum=G(inter.dense.bias))
         K.gemm(2, dh, x1, F, Hd, R, out=G(inter.dense.weight), accumulate=True, splits=K.splits_for(F, Hd, R))
-        d_x1 = K.gemm(1, dh, W16(inter.dense.weight), R, Hd, F, residual=d_pre2)
+        d_x1 = K.gemm(0, dh, W16T(inter.dense.weight), R, Hd, F, residual=d_pre2)
         del dh
         # x1 = LN(pre1), pre1 = x + dropout(dense(ctx))
         d_dense1 = d_dense2
         d_pre1 = K.layernorm_bwd(d_x1, pre1, R, Hd, ao.LayerNorm.weight.data, mean1, rstd1, G(ao.LayerNorm.weight),
                                  G(ao.LayerNorm.bias), dx2=d_dense1, dropout_p=p, seed=s1, colsum=G(ao.dense.bias))
         K.gemm(2, d_dense1, cx, Hd, Hd, R, out=G(ao.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))
-        d_cx = K.gemm(1, d_dense1, W16(ao.dense.weight), R, Hd, Hd)
+        d_cx = K.gemm(0, d_dense1, W16T(ao.dense.weight), R, Hd, Hd)
         dqkv = torch.empty_like(qkv)
         att.bwd(qkv, cx, d_cx, lse, dqkv, None)
         K.gemm(2, dqkv, x, 3 * Hd, Hd, R, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, R), rowsum_a=gbqkv)
-        dx = K.gemm(1, dqkv, wqkv16, R, Hd, 3 * Hd, residual=d_pre1)
+        dx = K.gemm(0, dqkv, W16T(att_m.query.weight), R, Hd, 3 * Hd, residual=d_pre1)
         return None, dx, None, None, None, None, None, None
 
 
@@ -432,15 +440,15 @@ class MLMHeadFn(torch.autograd.Function):
             d2 = pad[:, :V]
         K.gemm(2, d2, tn, V, Hd, R, out=G(dec.weight), accumulate=True, splits=K.splits_for(V, Hd, R), rowsum_a=G(dec.bias))
         # contraction over the vocabulary, rounded up to the row stride of the gradient buffer (30528 = 477 k-tiles): its
-        # padding columns are zeros (written by the loss kernel) and the weight rows past V lie in the arena (next parameter /
-        # zero slack), so the product is unchanged and the GEMM can take the large-tile path
+        # padding columns are zeros (written by the loss kernel) and so are those of the transposed weight copy, so the
+        # product is unchanged and the GEMM can take the large-tile path
         Kv = d2.stride(0) if (d2.stride(0) % 64 == 0 and d2.stride(0) - V < 64) else V
-        d_tn = K.gemm(1, d2, W16(dec.weight), R, Hd, Kv, splits=K.splits_nn(R, Hd, Kv))
+        d_tn = K.gemm(0, d2, W16T(dec.weight), R, Hd, Kv, splits=K.splits_nn(R, Hd, Kv))   # W^T rows are padded to 64 with zeros
         d_t = K.layernorm_bwd(d_tn, t, R, Hd, tr.LayerNorm.weight.data, mean, rstd, G(tr.LayerNorm.weight), G(tr.LayerNorm.bias))
         d_tpre = torch.empty((R, Hd), dtype=bf16, device=d_t.device)
         K.scale_mask_rows(d_t, R, Hd, out=d_tpre, colsum=G(tr.dense.bias), gelu_in=t_pre)
         K.gemm(2, d_tpre, x2, Hd, Hd, R, out=G(tr.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))
-        dx = K.gemm(1, d_tpre, W16(tr.dense.weight), R, Hd, Hd)
+        dx = K.gemm(0, d_tpre, W16T(tr.dense.weight), R, Hd, Hd)
         return None, dx.view(ctx.shp), None
 
 
@@ -480,7 +488,7 @@ class ScoreHeadFn(torch.autograd.Function):
                                G(lin2.bias))
         K.colsum(dz1, n, F, G(lin1.bias))
         K.gemm(2, dz1, xd, F, Hd, n, out=G(lin1.weight), accumulate=True, splits=1)
-        dx = K.gemm(1, dz1, W16(lin1.weight), n, Hd, F)
+        dx = K.gemm(0, dz1, W16T(lin1.weight), n, Hd, F)
         if dropout_p > 0:
             K.scale_mask_rows(dx, n, Hd, out=dx, dropout_p=dropout_p, seed=seed)
         return None, dx, None, None, None, None

@@ -331,6 +331,11 @@ def adamw(n, p, g, m, v, p16, block_group, lr4, wd4, b1, b2, eps, step, gradsq, 
             "lav_adamw_step")
 
 
+def transpose_batched(n_mats, descs_dev, total_tiles, src, dst):
+    L.check(L.lib.lav_transpose_bf16_batched(_s(), int(n_mats), _p(descs_dev), int(total_tiles), _p(src), _p(dst)),
+            "lav_transpose_bf16_batched")
+
+
 def cast_bf16(src, dst, n):
     L.check(L.lib.lav_cast_f32_to_bf16(_s(), int(n), _p(src), _p(dst)), "lav_cast_f32_to_bf16")
 

@@ -160,6 +160,62 @@ def test_gemm_splitk_large_tile_and_vocab_rounding():
     close(out1, ref, atol=3e-2, rtol=1e-2, what="vocab contraction, exact K")
 
 
+def test_batched_weight_transpose_and_arena_copy():
+    """lav_transpose_bf16_batched: ragged row counts (30522-like), narrow matrices, several matrices in one launch; and the
+    ParamArena keeps W^T (q/k/v fused into one (3H, H) matrix) in step with the bf16 working copy."""
+    import numpy as np
+    from lavender_amd._lib import MatDesc
+    shapes = [(1018, 64), (128, 96), (72, 200), (64, 64)]
+    src = torch.zeros(sum(r * c for r, c in shapes) + 64, device="cuda", dtype=torch.bfloat16)
+    descs, so, do, t0, mats = [], 0, 0, 0, []
+    for r, c in shapes:
+        m = rb(r, c, seed=r)
+        src[so:so + r * c] = m.reshape(-1)
+        ld = (r + 63) // 64 * 64
+        descs.append(MatDesc(so, do, r, c, ld, t0))
+        mats.append((m, do, ld))
+        so += (r * c + 7) // 8 * 8; do += c * ld; t0 += ((r + 63) // 64) * ((c + 63) // 64)
+    # offsets must be 8-aligned for the 16-byte loads: rebuild src with aligned offsets
+    src.zero_(); so = 0
+    for i, (r, c) in enumerate(shapes):
+        src[so:so + r * c] = mats[i][0].reshape(-1)
+        descs[i].src_off = so
+        so += (r * c + 7) // 8 * 8
+    dst = torch.zeros(do, device="cuda", dtype=torch.bfloat16)
+    arr = (MatDesc * len(descs))(*descs)
+    dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).cuda()
+    K().transpose_batched(len(descs), dev, t0, src, dst)
+    for (m, off, ld), (r, c) in zip(mats, shapes):
+        got = dst[off:off + c * ld].view(c, ld)
+        assert torch.equal(got[:, :r], m.t()), (r, c)
+        assert float(got[:, r:].abs().max()) == 0.0 if ld > r else True
+
+    import torch.nn as nn
+    from lavender_amd.arena import ParamArena
+
+    class Att(nn.Module):
+        def __init__(s):
+            super().__init__()
+            s.query, s.key, s.value = nn.Linear(64, 64), nn.Linear(64, 64), nn.Linear(64, 64)
+
+    class M(nn.Module):
+        def __init__(s):
+            super().__init__()
+            s.attention = nn.Module(); s.attention.self = Att()
+            s.fc = nn.Linear(64, 136)
+            s.word_embeddings = nn.Embedding(50, 64)
+    mod = M().cuda()
+    ar = ParamArena(mod, "cuda")
+    q = mod.attention.self.query.weight
+    fused = torch.cat([mod.attention.self.query.weight, mod.attention.self.key.weight, mod.attention.self.value.weight]).bfloat16()
+    assert q._lav16t.shape == (64, 192) and torch.equal(q._lav16t, fused.t())
+    assert torch.equal(mod.fc.weight._lav16t, mod.fc.weight.bfloat16().t()) and not hasattr(mod.word_embeddings.weight, "_lav16t")
+    with torch.no_grad():
+        mod.fc.weight.mul_(2.0)
+    ar.sync_half()
+    assert torch.equal(mod.fc.weight._lav16t, mod.fc.weight.bfloat16().t())
+
+
 def test_gemm_ragged_vocab_tail():
     M, V, Kd = 64, 1018, 128                         # V % 8 == 2 like 30522
     ld = (V + 7) // 8 * 8
