@@ -204,7 +204,7 @@ def main():
         dt = float(t.item())
     loss_vals = {k: float(v) for k, v in last.items()}
 
-    # ---- dominant-kernel roofline: every forward (NT) GEMM launch of one more step, HIP events on its stream ----
+    # ---- dominant-kernel roofline: every K-contiguous (layout 0) GEMM launch of one more step, HIP events on its stream ----
     # every rank runs the sampling step (it contains the gradient all-reduce); only rank 0 instruments and reports
     roof = None
     rec = []
@@ -243,7 +243,7 @@ def main():
         except Exception:
             traffic = None
         tot_fl = sum(v[1] for v in by.values()); tot_t = sum(v[2] for v in by.values())
-        roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T GEMMs: gemm_huge/big/gemm_kernel<NT>)",
+        roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T and input-gradient dy.(W^T)^T GEMMs: gemm_huge/big/gemm_kernel<NT>)",
                 "achieved": round(fl / tm / 1e12, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tm / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.md)",
