@@ -89,6 +89,19 @@ def test_state_dict_keys_match_reference(golden_dir):
     assert len(list(m.named_parameters())) == 221            # decoder.bias tied to predictions.bias
 
 
+def test_state_dict_keys_of_the_other_callers_match_reference(golden_dir):
+    """LAVENDER_Pretrain (fc.1 / fc.3 score head, no emb_task), LAVENDER_Retrieval_MLM and its eval subclass: same
+    state_dict keys as the reference classes (captured by tests/golden/make_goldens_variants.py)."""
+    from tests.helpers import Tok, make_args
+    from lavender_amd import LAVENDER_Pretrain, LAVENDER_Retrieval_MLM, LAVENDER_RetrievalMlmEval
+    ts = _g(golden_dir, "ts_micro_b5")
+    m = LAVENDER_Pretrain(make_args("micro", "micro", 5), Tok())
+    assert {k: str(tuple(v.shape)) for k, v in m.state_dict().items()} == dict(zip(ts["keys"].tolist(), ts["shapes"].tolist()))
+    rt = _g(golden_dir, "retr_micro_b3")
+    for cls in (LAVENDER_Retrieval_MLM, LAVENDER_RetrievalMlmEval):
+        assert set(cls(make_args("micro", "micro", 3), Tok()).state_dict()) == set(rt["keys"].tolist())
+
+
 def test_arena_order_groups_qkv():
     from lavender_amd.arena import _order
     names = []
