@@ -41,8 +41,8 @@ int lav_abi_version(void);
  * next multiple of 8 (their last 16-byte chunk is read whole).
  * Split-K (`splits` > 1): layout 2 with out_mode 2 (weight gradients), or layouts 0/1 with a bf16 output, no
  * epilogue and N % 8 == 0 (long-K problems with few output tiles, e.g. d_hidden = dlogits . W_dec).  Partial tiles
- * go to a process-wide fp32 workspace and are summed by a reduction pass, so split-K calls must be stream-ordered
- * with respect to each other (the product issues every GEMM on one stream).
+ * go to an fp32 workspace owned by the calling stream (one per stream, up to 8 streams; grown on demand) and are
+ * summed by a reduction pass on that stream.
  */
 typedef struct lav_gemm_epilogue {
     const float* bias;        /* [N] fp32 or NULL */

@@ -164,6 +164,8 @@ class Agent_Base:
     def backward_step(self, loss):
         """agent.py:235-250: backward, (all-reduce,) clip by global norm, AdamW, LR schedule, zero_grad."""
         loss.backward()
+        from .engine import dw_join
+        dw_join()                                          # weight-gradient kernels run on a side stream
         world = 1
         if self.dp is not None:
             self.dp.finish()

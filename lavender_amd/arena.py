@@ -164,12 +164,16 @@ class ParamArena:
 
     # -- optimizer ---------------------------------------------------------------------------------
     def zero_grad(self):
+        from .engine import dw_join
+        dw_join()
         self.grad.zero_()
         for p in self.params.values():
             if p.grad is None or p.grad.data_ptr() != p._lavg.data_ptr():
                 p.grad = p._lavg
 
     def adamw_step(self, lr4, wd4, step, max_norm, grad_div=1.0, betas=(0.9, 0.98), eps=1e-8):
+        from .engine import dw_join
+        dw_join()                                             # weight-gradient kernels run on a side stream
         if self.m is None:
             self.m = torch.zeros_like(self.master)
             self.v = torch.zeros_like(self.master)

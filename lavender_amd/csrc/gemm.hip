@@ -936,18 +936,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
     *(uint4*)(C + (long)row * ldc + col) = pack8(v);
 }
 
-// process-wide split-K workspace (grown on demand).  Calls of lav_gemm_bf16 with splits > 1 must therefore be
-// stream-ordered with respect to each other (the product issues every GEMM on one stream).
-static float* g_splitk_ws = nullptr;
-static size_t g_splitk_ws_bytes = 0;
-static float* splitk_workspace(size_t bytes) {
-    if (bytes > g_splitk_ws_bytes) {
-        if (g_splitk_ws) { (void)hipDeviceSynchronize(); (void)hipFree(g_splitk_ws); g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; }
-        size_t want = bytes < ((size_t)256 << 20) ? ((size_t)256 << 20) : bytes + bytes / 2;   // 256 MB up front: no re-allocation (device sync) once the step runs
-        if (hipMalloc((void**)&g_splitk_ws, want) != hipSuccess) { (void)hipGetLastError(); g_splitk_ws = nullptr; return nullptr; }
-        g_splitk_ws_bytes = want;
+// split-K workspaces, one per stream that issues split-K GEMMs (the product uses two: the main stream and the
+// weight-gradient side stream); grown on demand.  Calls on the SAME stream are ordered, so they can share a buffer.
+struct SplitKWs { void* stream; float* ptr; size_t bytes; };
+static SplitKWs g_splitk[8] = {};
+static float* splitk_workspace(void* stream, size_t bytes) {
+    SplitKWs* e = nullptr;
+    for (auto& w : g_splitk) if (w.ptr && w.stream == stream) { e = &w; break; }
+    if (!e) for (auto& w : g_splitk) if (!w.ptr) { e = &w; e->stream = stream; break; }
+    if (!e) e = &g_splitk[0];                            // more than 8 streams: share (callers must then order those streams)
+    if (bytes > e->bytes) {
+        if (e->ptr) { (void)hipDeviceSynchronize(); (void)hipFree(e->ptr); e->ptr = nullptr; e->bytes = 0; }
+        size_t want = bytes < ((size_t)256 << 20) ? ((size_t)256 << 20) : bytes + bytes / 2;   // 256 MB up front: no re-allocation once the step runs
+        if (hipMalloc((void**)&e->ptr, want) != hipSuccess) { (void)hipGetLastError(); e->ptr = nullptr; return nullptr; }
+        e->bytes = want;
     }
-    return g_splitk_ws;
+    return e->ptr;
 }
 
 // test hook: route everything through the 128x128 kernel (set by LAV_GEMM_SMALL=1)
@@ -1059,7 +1063,7 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         const int rpt = sk_huge ? BIG_BM : BM;
         const int ws_tiles = ((M + rpt - 1) / rpt) * ((N + BN - 1) / BN);
         if (sk) {
-            g.ws = splitk_workspace((size_t)splits * ws_tiles * rpt * BN * sizeof(float));
+            g.ws = splitk_workspace(stream, (size_t)splits * ws_tiles * rpt * BN * sizeof(float));
             LAV_REQUIRE(g.ws, "lav_gemm_bf16: split-K workspace allocation failed");
             g.ws_tiles = ws_tiles;
         }
@@ -1090,7 +1094,7 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         if (g.e.out_mode == 2 && !lav_gemm_atomic_flush) {
             if (splits == 1) g.owner = 1;
             else if ((N % 4) == 0 && (ldc % 4) == 0) {
-                float* ws = splitk_workspace((size_t)splits * ws_tiles * rpt * BN * sizeof(float));
+                float* ws = splitk_workspace(stream, (size_t)splits * ws_tiles * rpt * BN * sizeof(float));
                 if (ws) { g.ws = ws; g.ws_tiles = ws_tiles; reduce = true; }
             }
         }

@@ -69,6 +69,9 @@ class ArenaReducer:
 
     def _reduce(self, ranges):
         g = self.model.arena().grad
+        if g.is_cuda:
+            from .engine import dw_join
+            dw_join()                                         # the ranges' weight gradients come from the dW side stream
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):

@@ -9,6 +9,8 @@ bookkeeping only -- no arithmetic runs in ATen.
 `anchor` is a 1-element requires-grad tensor (arena.anchor) threaded through every stage so that autograd runs
 the stage's backward even though its parameters are not autograd inputs.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -34,6 +36,42 @@ def W16T(p):
 
 def G(p):
     return p._lavg
+
+
+# ---- weight-gradient GEMMs on a side stream --------------------------------------------------------------------------
+# dW = dy^T x is never needed before the optimizer, so it does not have to sit in the dy -> dx dependency chain: issued on
+# a second stream it fills the CUs the main stream leaves idle (partial last rounds of 1-block-per-CU GEMMs, kernel
+# ramps and tails between ~1500 dependent launches per step).  All dW kernels share that ONE stream, so their
+# accumulations into the gradient arena (and the split-K workspace of that stream) stay ordered among themselves.
+_DW_SIDE = os.environ.get("LAV_DW_STREAM", "1") != "0"
+_dw_streams = {}
+
+
+def dw_stream(device):
+    st = _dw_streams.get(device)
+    if st is None:
+        st = _dw_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def dw_gemm(A, Bm, M, N, Kd, **kw):
+    """layout-2 GEMM accumulating into the gradient arena; A / Bm may be freed by the caller right after this returns."""
+    if not _DW_SIDE:
+        return K.gemm(2, A, Bm, M, N, Kd, **kw)
+    side = dw_stream(A.device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        K.gemm(2, A, Bm, M, N, Kd, **kw)
+    for t in (A, Bm, kw.get("k_keep")):
+        if t is not None:
+            t.record_stream(side)
+
+
+def dw_join(device=None):
+    """main stream waits for every weight-gradient kernel issued so far (before the gradients are read)."""
+    for dev, st in _dw_streams.items():
+        if device is None or dev == device:
+            torch.cuda.current_stream(dev).wait_stream(st)
 
 
 def _keep(ctx):
@@ -71,7 +109,8 @@ class PatchEmbedFn(torch.autograd.Function):
         dx = dx.contiguous()
         dy = K.layernorm_bwd(dx, y, M, E, mod.norm.weight.data, mean, rstd, G(mod.norm.weight), G(mod.norm.bias),
                              colsum=G(mod.proj.bias))
-        K.gemm(2, dy, cols, E, 96, M, out=G(mod.proj.weight).view(E, 96), accumulate=True, splits=K.splits_for(E, 96, M))
+        dw_gemm(dy, cols, E, 96, M, out=G(mod.proj.weight).view(E, 96), accumulate=True, splits=K.splits_for(E, 96, M))
+        dw_join(dy.device)                                # last stage of the backward: every gradient is final on the main stream
         return None, None, None, None
 
 
@@ -123,22 +162,22 @@ class SwinBlockFn(torch.autograd.Function):
         M, C = x.shape
         dy = dy.contiguous()
         # --- MLP branch: out = x_mid + s * fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------
-        K.gemm(2, dy, h, C, 4 * C, M, out=G(mlp.fc2.weight), accumulate=True, k_keep=dp_mlp, k_rows_per_group=rpg,
+        dw_gemm(dy, h, C, 4 * C, M, out=G(mlp.fc2.weight), accumulate=True, k_keep=dp_mlp, k_rows_per_group=rpg,
                alpha=alpha if dp_mlp is not None else 1.0, splits=K.splits_for(C, 4 * C, M, dp_mlp is not None), rowsum_a=G(mlp.fc2.bias))
         dh = K.gemm(0, dy, W16T(mlp.fc2.weight), M, 4 * C, C, gelu_in=h_pre, gelu_in_is_grad=True, row_scale=dp_mlp,
                     rows_per_group=rpg, colsum=G(mlp.fc1.bias))
-        K.gemm(2, dh, y2, 4 * C, C, M, out=G(mlp.fc1.weight), accumulate=True, splits=K.splits_for(4 * C, C, M))
+        dw_gemm(dh, y2, 4 * C, C, M, out=G(mlp.fc1.weight), accumulate=True, splits=K.splits_for(4 * C, C, M))
         d_y2 = K.gemm(0, dh, W16T(mlp.fc1.weight), M, C, 4 * C)
         del dh
         d_mid = K.layernorm_bwd(d_y2, x_mid, M, C, blk.norm2.weight.data, mean2, rstd2, G(blk.norm2.weight), G(blk.norm2.bias),
                                 add_in=dy)
         # --- attention branch: x_mid = x + s * proj(attn(qkv(LN1(x)))) ---------------------------------
-        K.gemm(2, d_mid, ao, C, C, M, out=G(a.proj.weight), accumulate=True, k_keep=dp_attn, k_rows_per_group=rpg,
+        dw_gemm(d_mid, ao, C, C, M, out=G(a.proj.weight), accumulate=True, k_keep=dp_attn, k_rows_per_group=rpg,
                alpha=alpha if dp_attn is not None else 1.0, splits=K.splits_for(C, C, M, dp_attn is not None), rowsum_a=G(a.proj.bias))
         d_ao = K.gemm(0, d_mid, W16T(a.proj.weight), M, C, C, row_scale=dp_attn, rows_per_group=rpg)
         dqkv = torch.empty_like(qkv)
         att.bwd(qkv, ao, d_ao, lse, dqkv, G(a.relative_position_bias_table))
-        K.gemm(2, dqkv, y1, 3 * C, C, M, out=G(a.qkv.weight), accumulate=True, splits=K.splits_for(3 * C, C, M),
+        dw_gemm(dqkv, y1, 3 * C, C, M, out=G(a.qkv.weight), accumulate=True, splits=K.splits_for(3 * C, C, M),
                rowsum_a=G(a.qkv.bias))
         d_y1 = K.gemm(0, dqkv, W16T(a.qkv.weight), M, C, 3 * C)
         dx = K.layernorm_bwd(d_y1, x, M, C, blk.norm1.weight.data, mean1, rstd1, G(blk.norm1.weight), G(blk.norm1.bias),
@@ -170,7 +209,7 @@ class PatchMergeFn(torch.autograd.Function):
         x, y, mean, rstd = ctx.saved_tensors
         rows = y.shape[0]
         dout = dout.contiguous()
-        K.gemm(2, dout, y, 2 * C, 4 * C, rows, out=G(mod.reduction.weight), accumulate=True, splits=K.splits_for(2 * C, 4 * C, rows))
+        dw_gemm(dout, y, 2 * C, 4 * C, rows, out=G(mod.reduction.weight), accumulate=True, splits=K.splits_for(2 * C, 4 * C, rows))
         d_y = K.gemm(0, dout, W16T(mod.reduction.weight), rows, 4 * C, 2 * C)
         dx = K.layernorm_bwd(d_y, x, rows, 4 * C, mod.norm.weight.data, mean, rstd, G(mod.norm.weight), G(mod.norm.bias),
                              gather=(H, W, C))
@@ -238,7 +277,7 @@ class VideoEmbedFn(torch.autograd.Function):
                           G(enc.norm.weight), G(enc.norm.bias))
         if enc.fc is None:
             return None, dfeat, None, None, None, None
-        K.gemm(2, dfeat, tok, Hd, Cl, M, out=G(enc.fc.weight), accumulate=True, splits=K.splits_for(Hd, Cl, M),
+        dw_gemm(dfeat, tok, Hd, Cl, M, out=G(enc.fc.weight), accumulate=True, splits=K.splits_for(Hd, Cl, M),
                rowsum_a=G(enc.fc.bias))
         dtok = K.gemm(0, dfeat, W16T(enc.fc.weight), M, Cl, Hd)
         return None, dtok, None, None, None, None
@@ -382,20 +421,20 @@ class BertLayerFn(torch.autograd.Function):
         d_dense2 = torch.empty((R, Hd), dtype=bf16, device=x.device)
         d_pre2 = K.layernorm_bwd(dy, pre2, R, Hd, outp.LayerNorm.weight.data, mean2, rstd2, G(outp.LayerNorm.weight),
                                  G(outp.LayerNorm.bias), dx2=d_dense2, dropout_p=p, seed=s2, colsum=G(outp.dense.bias))
-        K.gemm(2, d_dense2, h, Hd, F, R, out=G(outp.dense.weight), accumulate=True, splits=K.splits_for(Hd, F, R))
+        dw_gemm(d_dense2, h, Hd, F, R, out=G(outp.dense.weight), accumulate=True, splits=K.splits_for(Hd, F, R))
         dh = K.gemm(0, d_dense2, W16T(outp.dense.weight), R, F, Hd, gelu_in=h_pre, gelu_in_is_grad=True, colsum=G(inter.dense.bias))
-        K.gemm(2, dh, x1, F, Hd, R, out=G(inter.dense.weight), accumulate=True, splits=K.splits_for(F, Hd, R))
+        dw_gemm(dh, x1, F, Hd, R, out=G(inter.dense.weight), accumulate=True, splits=K.splits_for(F, Hd, R))
         d_x1 = K.gemm(0, dh, W16T(inter.dense.weight), R, Hd, F, residual=d_pre2)
         del dh
         # x1 = LN(pre1), pre1 = x + dropout(dense(ctx))
-        d_dense1 = d_dense2
+        d_dense1 = torch.empty_like(d_dense2) if _DW_SIDE else d_dense2     # the side stream may still read d_dense2
         d_pre1 = K.layernorm_bwd(d_x1, pre1, R, Hd, ao.LayerNorm.weight.data, mean1, rstd1, G(ao.LayerNorm.weight),
                                  G(ao.LayerNorm.bias), dx2=d_dense1, dropout_p=p, seed=s1, colsum=G(ao.dense.bias))
-        K.gemm(2, d_dense1, cx, Hd, Hd, R, out=G(ao.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))
+        dw_gemm(d_dense1, cx, Hd, Hd, R, out=G(ao.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))
         d_cx = K.gemm(0, d_dense1, W16T(ao.dense.weight), R, Hd, Hd)
         dqkv = torch.empty_like(qkv)
         att.bwd(qkv, cx, d_cx, lse, dqkv, None)
-        K.gemm(2, dqkv, x, 3 * Hd, Hd, R, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, R), rowsum_a=gbqkv)
+        dw_gemm(dqkv, x, 3 * Hd, Hd, R, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, R), rowsum_a=gbqkv)
         dx = K.gemm(0, dqkv, W16T(att_m.query.weight), R, Hd, 3 * Hd, residual=d_pre1)
         return None, dx, None, None, None, None, None, None
 
@@ -438,7 +477,7 @@ class MLMHeadFn(torch.autograd.Function):
             pad = torch.zeros((R, ld), dtype=bf16, device=d2.device)
             pad[:, :V].copy_(d2)
             d2 = pad[:, :V]
-        K.gemm(2, d2, tn, V, Hd, R, out=G(dec.weight), accumulate=True, splits=K.splits_for(V, Hd, R), rowsum_a=G(dec.bias))
+        dw_gemm(d2, tn, V, Hd, R, out=G(dec.weight), accumulate=True, splits=K.splits_for(V, Hd, R), rowsum_a=G(dec.bias))
         # contraction over the vocabulary, rounded up to the row stride of the gradient buffer (30528 = 477 k-tiles): its
         # padding columns are zeros (written by the loss kernel) and so are those of the transposed weight copy, so the
         # product is unchanged and the GEMM can take the large-tile path
@@ -447,7 +486,7 @@ class MLMHeadFn(torch.autograd.Function):
         d_t = K.layernorm_bwd(d_tn, t, R, Hd, tr.LayerNorm.weight.data, mean, rstd, G(tr.LayerNorm.weight), G(tr.LayerNorm.bias))
         d_tpre = torch.empty((R, Hd), dtype=bf16, device=d_t.device)
         K.scale_mask_rows(d_t, R, Hd, out=d_tpre, colsum=G(tr.dense.bias), gelu_in=t_pre)
-        K.gemm(2, d_tpre, x2, Hd, Hd, R, out=G(tr.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))
+        dw_gemm(d_tpre, x2, Hd, Hd, R, out=G(tr.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))
         dx = K.gemm(0, d_tpre, W16T(tr.dense.weight), R, Hd, Hd)
         return None, dx.view(ctx.shp), None
 
@@ -487,7 +526,7 @@ class ScoreHeadFn(torch.autograd.Function):
         dz1 = K.pair_score_bwd(dlogits, n, F, O, inv_temp, h, act_grad, W16(lin2.weight).view(F), G(lin2.weight).view(F),
                                G(lin2.bias))
         K.colsum(dz1, n, F, G(lin1.bias))
-        K.gemm(2, dz1, xd, F, Hd, n, out=G(lin1.weight), accumulate=True, splits=1)
+        dw_gemm(dz1, xd, F, Hd, n, out=G(lin1.weight), accumulate=True, splits=1)
         dx = K.gemm(0, dz1, W16T(lin1.weight), n, Hd, F)
         if dropout_p > 0:
             K.scale_mask_rows(dx, n, Hd, out=dx, dropout_p=dropout_p, seed=seed)

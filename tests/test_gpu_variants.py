@@ -296,3 +296,49 @@ def test_loss_aware_head_same_loss_and_gradients():
     rel = ((ga - gb).norm() / ga.norm()).item()
     print("gradient arena rel diff", rel)
     assert rel < 1e-2
+
+
+def test_weight_gradient_side_stream_is_race_free():
+    """The dW GEMMs run on a second stream (engine.dw_gemm).  Weight gradients come from plain read-modify-writes (no
+    atomics), so with identical seeds they must be BITWISE equal to the single-stream run; the test repeats the step to
+    give a lifetime / ordering race a chance to show (buffers are recycled by the caching allocator between steps)."""
+    from tests.helpers import Tok, make_args
+    import lavender_amd as LA
+    import lavender_amd.engine as E
+    from lavender_amd import hip as K
+    from lavender_amd.dist import set_seed
+    B = 4
+    set_seed(88)
+    args = make_args("micro", "micro", B)
+    m = LA.LAVENDER_Pretrain_MLM(args, Tok()).cuda()
+    ar = m.arena()
+    ag = LA.Agent_Pretrain_MLM(args, m)
+    b = make_batch(B, vocab=BERT_CFGS["micro"]["vocab"])
+    torch.manual_seed(5)
+    b.update(ag.masking(b["txt"], b["mask"]))
+    batch = ag.prepare_batch(b)
+    wnames = [n for n, p in m.named_parameters() if p.dim() == 2 and n.endswith("weight") and "embeddings" not in n]
+
+    def run(side):
+        E._DW_SIDE = side
+        K.reseed(4321)
+        np.random.seed(3)
+        m.train()
+        ar.zero_grad()
+        out = m(batch)
+        ls = (ag.loss_func(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten(), batch["_n_mtm"]) +
+              ag.loss_func(out["out_vtm"].flatten(0, 1), out["ans_vtm"].flatten(), B * 4))
+        ls.backward()
+        torch.cuda.synchronize()
+        return {n: ar.params[n].grad.clone() for n in wnames}, ar.grad.clone()
+
+    keep = E._DW_SIDE
+    try:
+        ref, ref_all = run(False)
+        for rep in range(4):
+            got, got_all = run(True)
+            bad = [n for n in wnames if not torch.equal(got[n], ref[n])]
+            assert not bad, (rep, bad[:5])
+            assert ((got_all - ref_all).norm() / ref_all.norm()).item() < 1e-4      # the rest: atomics, order-dependent rounding
+    finally:
+        E._DW_SIDE = keep
