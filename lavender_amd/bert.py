@@ -153,10 +153,10 @@ class BertOnlyMLMHead(nn.Module):
         self.predictions = BertLMPredictionHead(cfg)
         self._arena_of = None
 
-    def forward(self, sequence_output):
+    def forward(self, sequence_output, split=None):
         from . import engine as E
         arena = self._arena_of()
-        return E.MLMHeadFn.apply(arena.anchor, sequence_output, self)
+        return E.MLMHeadFn.apply(arena.anchor, sequence_output, self, split)
 
 
 def load_hf_state(path, prefix_map):

@@ -443,7 +443,10 @@ class MLMHeadFn(torch.autograd.Function):
     """BertOnlyMLMHead (main_pretrain_mlm.py:46-48,69,115): dense+GELU, LayerNorm, vocab projection."""
 
     @staticmethod
-    def forward(ctx, anchor, x, head):
+    def forward(ctx, anchor, x, head, split=None):
+        """split = n0: x is (n, X, H) holding two groups of sequences (the MTM and the VTM pairs run through the encoder as one
+        batch); returns the logits of x[:n0] and x[n0:] as two views of ONE buffer, so that each loss can overwrite its part
+        with its gradient in place and the backward below still sees a single (rows, vocab) operand."""
         shp = x.shape
         Hd = shp[-1]
         x2 = x.reshape(-1, Hd).contiguous()
@@ -458,18 +461,33 @@ class MLMHeadFn(torch.autograd.Function):
         ld = (V + 7) // 8 * 8
         buf = torch.empty((R, ld), dtype=bf16, device=x.device)
         K.gemm(0, tn, W16(dec.weight), R, V, Hd, out=buf, bias=dec.bias.data)
-        ctx.head, ctx.shp = head, shp
+        ctx.head, ctx.shp, ctx.split = head, shp, split
         ctx.save_for_backward(x2, t_pre, t, mean, rstd, tn)
-        return buf[:, :V].view(*shp[:-1], V)
+        if split is None:
+            return buf[:, :V].view(*shp[:-1], V)
+        assert x.dim() == 3 and 0 < split < shp[0]
+        r0 = split * shp[1]
+        ctx.buf = buf if keep else None
+        return buf[:r0, :V].view(split, shp[1], V), buf[r0:, :V].view(shp[0] - split, shp[1], V)
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dlogits, dlogits_b=None):
         head = ctx.head
         x2, t_pre, t, mean, rstd, tn = ctx.saved_tensors
         R, Hd = x2.shape
         tr, dec = head.predictions.transform, head.predictions.decoder
         V = dec.weight.shape[0]
         ld = (V + 7) // 8 * 8
+        if ctx.split is not None:
+            buf, r0 = ctx.buf, ctx.split * ctx.shp[1]
+            same = (dlogits is not None and dlogits_b is not None and dlogits.data_ptr() == buf.data_ptr() and
+                    dlogits_b.data_ptr() == buf[r0:].data_ptr() and dlogits.stride(-2) == ld and dlogits_b.stride(-2) == ld)
+            if same:
+                dlogits = buf[:, :V]                       # both losses wrote their gradient into their part of the logits buffer
+            else:
+                parts = [torch.zeros((n, V), dtype=bf16, device=x2.device) if g is None else g.reshape(n, V)
+                         for g, n in ((dlogits, r0), (dlogits_b, R - r0))]
+                dlogits = torch.cat(parts, 0)
         d2 = dlogits.reshape(R, V) if dlogits.is_contiguous() else dlogits
         if d2.dim() != 2:
             d2 = d2.reshape(R, V)
@@ -488,7 +506,7 @@ class MLMHeadFn(torch.autograd.Function):
         K.scale_mask_rows(d_t, R, Hd, out=d_tpre, colsum=G(tr.dense.bias), gelu_in=t_pre)
         dw_gemm(d_tpre, x2, Hd, Hd, R, out=G(tr.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))
         dx = K.gemm(0, d_tpre, W16T(tr.dense.weight), R, Hd, Hd)
-        return None, dx.view(ctx.shp), None
+        return None, dx.view(ctx.shp), None, None
 
 
 class ScoreHeadFn(torch.autograd.Function):

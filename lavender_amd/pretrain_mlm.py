@@ -12,6 +12,10 @@ from .bert import BertConfigLite, BertOnlyMLMHead, load_hf_state
 from .model import LAVENDER_Base
 
 
+import os as _os
+_MERGE_PASSES = _os.environ.get("LAV_MERGE_PASSES", "1") != "0"
+
+
 def vtm_pairs(B, O):
     """Pair list of main_pretrain_mlm.py:74-106: per sample i -> (i,i,true) then O-1 negatives drawn with ONE
     np.random.permutation([j != i]) -- same RNG call sequence, hence the same negatives, as the reference."""
@@ -65,30 +69,37 @@ class LAVENDER_Pretrain_MLM(LAVENDER_Base):
         Lv = (1 + _h * _w) * _T
 
         feat_img, mask_img, feat_txt, mask_txt = self.go_feat(img, txt, mask, vt_mask=vt_mask)
-        out, _ = self.go_cross(feat_img, mask_img, feat_txt, mask_txt)
+        # The reference runs the fusion encoder + head twice (main_pretrain_mlm.py:67-69 on the B true pairs, :111-115 on
+        # the B*O matching pairs).  Here both groups go through as ONE batch of B + B*O sequences (same arithmetic per
+        # sequence, half the kernel launches, no under-filled 32-sequence GEMMs); the head returns the two logit tensors.
+        vi, ti, tr = vtm_pairs(_B, _O)
+        lab_vtm = torch.where(torch.from_numpy(tr), self.true_token_id, self.false_token_id)
+        if not _MERGE_PASSES:
+            out, _ = self.go_cross(feat_img, mask_img, feat_txt, mask_txt)
+            out_mtm = self.fc_mtm(out[:, Lv:])
+            out, _ = self.go_cross_pairs(feat_img, mask_img, feat_txt, mask_txt, vi, ti)
+            out_vtm = self.fc_mtm(out[:, Lv:])
+            ans_vtm = torch.full((_B * _O, _X), -1, dtype=torch.long)
+            ans_vtm[:, -1] = lab_vtm
+            return {"out_vtm": out_vtm, "out_mtm": out_mtm, "ans_vtm": ans_vtm.to(txt.device, non_blocking=True), "ans_mtm": ans_mtm}
+        vi_all = np.concatenate([np.arange(_B), vi])
+        ti_all = np.concatenate([np.arange(_B), ti])
+        out, _ = self.go_cross_pairs(feat_img, mask_img, feat_txt, mask_txt, vi_all, ti_all)
+        _L, _n = Lv + _X, _B + _B * _O
         # opt-in (args.loss_aware_head, training only): head + loss on the supervised positions only -- same loss and
         # gradients, ~8x less vocabulary GEMM and no (n, X, vocab) logits; the default keeps the reference's full outputs
         lab_cpu = batch["_ans_mtm_cpu"]
         aware = self.training and bool(getattr(self.args, "loss_aware_head", False)) and lab_cpu is not None
         rows_b, rows_x = (np.nonzero(lab_cpu.numpy() != -1) if aware else (None, None))
         aware = aware and len(rows_b) > 0
-        _L = Lv + _X
         if aware:
-            h = E.RowGatherFn.apply(out.reshape(_B * _L, -1), rows_b * _L + Lv + rows_x)
-            out_mtm = self.fc_mtm(h)
+            rows = np.concatenate([rows_b * _L + Lv + rows_x, (_B + np.arange(_B * _O)) * _L + _L - 1])
+            logits = self.fc_mtm(E.RowGatherFn.apply(out.reshape(_n * _L, -1), rows))
+            out_mtm, out_vtm = logits[:len(rows_b)], logits[len(rows_b):]
             ans_mtm = lab_cpu[rows_b, rows_x].to(txt.device, non_blocking=True)
-        else:
-            out_mtm = self.fc_mtm(out[:, Lv:])
-
-        vi, ti, tr = vtm_pairs(_B, _O)
-        out, _ = self.go_cross_pairs(feat_img, mask_img, feat_txt, mask_txt, vi, ti)
-        lab_vtm = torch.where(torch.from_numpy(tr), self.true_token_id, self.false_token_id)
-        if aware:
-            h = E.RowGatherFn.apply(out.reshape(_B * _O * _L, -1), np.arange(_B * _O) * _L + _L - 1)
-            out_vtm = self.fc_mtm(h)
             ans_vtm = lab_vtm.to(txt.device, non_blocking=True)
         else:
-            out_vtm = self.fc_mtm(out[:, Lv:])
+            out_mtm, out_vtm = self.fc_mtm(out[:, Lv:], split=_B)
             ans_vtm = torch.full((_B * _O, _X), -1, dtype=torch.long)
             ans_vtm[:, -1] = lab_vtm
             ans_vtm = ans_vtm.to(txt.device, non_blocking=True)
