@@ -226,6 +226,17 @@ def main():
         K.gemm = timed
     run_step(0)
     torch.cuda.synchronize()
+    rec_shared = rec
+    # the same sampling once more with the weight-gradient side stream off: the timed steps overlap dW kernels with the
+    # chain, so the per-launch durations above include sharing the CUs; this pass times each GEMM launch on its own
+    import lavender_amd.engine as _E
+    rec = []
+    _side = _E._DW_SIDE
+    _E._DW_SIDE = False
+    run_step(0)
+    torch.cuda.synchronize()
+    _E._DW_SIDE = _side
+    rec_iso, rec = rec, rec_shared
     K.gemm = orig
     if rank == 0:
         by = {}
@@ -243,12 +254,20 @@ def main():
         except Exception:
             traffic = None
         tot_fl = sum(v[1] for v in by.values()); tot_t = sum(v[2] for v in by.values())
+        iso = [0, 0.0, 0.0]
+        for lay_i, fl_i, e0_i, e1_i, _nb_i in rec_iso:
+            if lay_i == 0:
+                iso[0] += 1; iso[1] += fl_i; iso[2] += e0_i.elapsed_time(e1_i) * 1e-3
         roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T and input-gradient dy.(W^T)^T GEMMs: gemm_huge/big/gemm_kernel<NT>)",
                 "achieved": round(fl / tm / 1e12, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tm / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.md)",
                 "algorithmic_bytes_per_launch": round(nb / n),
                 "launches_per_step": n, "avg_launch_us": round(tm / n * 1e6, 2), "avg_launch_gflop": round(fl / n / 1e9, 3),
+                "note": "achieved / avg_launch_us are measured in the shipped configuration, where weight-gradient GEMMs of a second "
+                        "stream share the CUs with these launches; `isolated` = same launches with that stream off",
+                "isolated": {"achieved": round(iso[1] / iso[2] / 1e12, 2), "frac": round(iso[1] / iso[2] / 1e12 / PEAK_BF16_TFLOPS, 4),
+                             "avg_launch_us": round(iso[2] / max(iso[0], 1) * 1e6, 2)},
                 "all_gemm_layouts": {"launches": sum(v[0] for v in by.values()), "tflops": round(tot_fl / tot_t / 1e12, 2),
                                      "gemm_time_ms_per_step": round(tot_t * 1e3, 2)}}
     if world > 1:
