@@ -1043,7 +1043,8 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     const long t_small = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const long t_big = (long)((M + BIG_BM - 1) / BIG_BM) * ((N + BN - 1) / BN);
     const long t_huge = (long)((M + BIG_BM - 1) / BIG_BM) * (N / 256);
-    const double f_small = fill(t_small, 512, 0.80), f_big = fill(t_big, 256, 0.88);
+    static const double w_big = getenv("LAV_GEMM_BIG_W") ? atof(getenv("LAV_GEMM_BIG_W")) : 0.80;    // probe hook; 0.80 measured best once the dW stream fills partial rounds (0.88 before)
+    const double f_small = fill(t_small, 512, 0.80), f_big = fill(t_big, 256, w_big);
     const double f_huge = (N % 256) == 0 ? fill(t_huge, 256, 1.0) : 0.0;
     if (big && !lav_gemm_no_huge && f_huge >= f_big && f_huge >= f_small) {
         g.k_per_split = K;
