@@ -107,8 +107,8 @@ def cpu_baseline(timeout_s=240):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 32 (cfg2), 8 (cfg4, cfg5)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                     help="BASELINE.json configs: cfg2 = headline (Swin-B 224, pretrain MLM); cfg4 = Swin-L 384^2 pretrain; "

@@ -69,6 +69,10 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
     return out[:, :N] if out.shape[-1] != N else out
 
 
+import os as _os
+_TN_BLOCKS = int(_os.environ.get("LAV_TN_BLOCKS", "192"))      # probe hook: target blocks per weight-gradient GEMM
+
+
 def splits_for(M, N, K, keep=False):
     """split-K factor for weight-gradient GEMMs, matched to the kernel lav_gemm_bf16 picks for the shape (256x256 tiles
     when M >= 256, N % 256 == 0 and K % 64 == 0; 256x128 when only N % 256 fails; else 128x128).  Measured on MI355X
@@ -76,7 +80,7 @@ def splits_for(M, N, K, keep=False):
     partial tiles go to a workspace and are summed by one reduction pass, so extra splits are cheap."""
     if M >= 256 and K % 64 == 0:
         tiles = ((M + 255) // 256) * (N // 256 if N % 256 == 0 else (N + 127) // 128)
-        return int(max(1, min(256 // tiles if tiles <= 256 else 1, K // 256)))
+        return int(max(1, min(_TN_BLOCKS // tiles if tiles <= _TN_BLOCKS else 1, K // 256)))
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 200:
         return 1
