@@ -65,8 +65,9 @@ typedef struct lav_gemm_epilogue {
     int k_rows_per_group;
     float* rowsum_a;          /* layout 2 only: fp32 [M] += alpha * sum_k A[k, m] -- the bias gradient sum(dy), fused
                                  into the weight-gradient GEMM on the matrix cores (no extra pass over dy) */
-    int preact_is_grad;       /* forward: store act'(z) instead of z (the backward then needs one multiply, no erf) */
-    int gelu_in_is_grad;      /* backward: gelu_in already holds GELU'(z) */
+    int preact_is_grad;       /* forward: store act'(z) instead of z (the backward then needs one multiply, no erf); 2 = GELU only,
+                                 as ONE BYTE per element: q = round((g + 0.25) * 256 / 1.5), preact is uint8 [M, ldp] */
+    int gelu_in_is_grad;      /* backward: gelu_in already holds GELU'(z) (1: bf16, 2: the one-byte code above, ldg in bytes) */
 } lav_gemm_epilogue;
 
 int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B, long ldb,

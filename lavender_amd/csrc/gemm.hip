@@ -216,7 +216,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             const int grow = m0 + etid / CH + RPP * (j0 + u);
             pre_g[u] = make_uint4(0, 0, 0, 0); pre_r[u] = pre_g[u];
             if (inside && grow < g.M) {
-                if (has_gin) pre_g[u] = *(const uint4*)((const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol);
+                if (has_gin) {
+                    if (e.gelu_in_is_grad == 2) {                 // one byte per element (see gq_pack8)
+                        const uint2 q = *(const uint2*)((const uint8_t*)e.gelu_in + (long)grow * e.ldg + gcol);
+                        pre_g[u].x = q.x; pre_g[u].y = q.y;
+                    } else {
+                        pre_g[u] = *(const uint4*)((const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol);
+                    }
+                }
                 if (has_res) pre_r[u] = *(const uint4*)((const bf16_t*)e.residual + (long)grow * e.ldr + gcol);
             }
         }
@@ -242,9 +249,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
                 float gp[8];
 #pragma unroll
                 for (int x = 0; x < 8; ++x) gelu_and_grad(v[x], v[x], gp[x]);
-                bf16_t* p = (bf16_t*)e.preact + (long)grow * e.ldp + gcol;
-                if (full) *(uint4*)p = pack8(gp);
-                else for (int x = 0; x < ncols; ++x) p[x] = f2bf(gp[x]);
+                if (e.preact_is_grad == 2) {
+                    uint8_t* p = (uint8_t*)e.preact + (long)grow * e.ldp + gcol;
+                    const uint2 q = gq_pack8(gp);
+                    if (full) *(uint2*)p = q;
+                    else for (int x = 0; x < ncols; ++x) p[x] = (uint8_t)(((x < 4 ? q.x : q.y) >> (8 * (x & 3))) & 0xffu);
+                } else {
+                    bf16_t* p = (bf16_t*)e.preact + (long)grow * e.ldp + gcol;
+                    if (full) *(uint4*)p = pack8(gp);
+                    else for (int x = 0; x < ncols; ++x) p[x] = f2bf(gp[x]);
+                }
             } else {
 #pragma unroll
                 for (int x = 0; x < 8; ++x) v[x] = gelu_f(v[x]);
@@ -265,7 +279,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         if (has_gin) {
             const bf16_t* p = (const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol;
             float h[8];
-            if (full) unpack8(pre_g[u], h);
+            if (e.gelu_in_is_grad == 2) {
+                if (full) gq_unpack8(make_uint2(pre_g[u].x, pre_g[u].y), h);
+                else for (int x = 0; x < 8; ++x)
+                    h[x] = x < ncols ? fmaf((float)((const uint8_t*)e.gelu_in)[(long)grow * e.ldg + gcol + x], 1.0f / LAV_GQ_SCALE, -LAV_GQ_OFF) : 0.f;
+            } else if (full) unpack8(pre_g[u], h);
             else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? bf2f(p[x]) : 0.f;
             if (!GEN || e.gelu_in_is_grad) {
 #pragma unroll

@@ -44,6 +44,8 @@ def G(p):
 # ramps and tails between ~1500 dependent launches per step).  All dW kernels share that ONE stream, so their
 # accumulations into the gradient arena (and the split-K workspace of that stream) stay ordered among themselves.
 _DW_SIDE = os.environ.get("LAV_DW_STREAM", "1") != "0"
+_GQ = 2 if os.environ.get("LAV_GELU_GRAD_U8", "0") != "0" else 1          # GELU' storage: 1 = bf16 (default), 2 = one byte per element (measured 0.8 ms/step SLOWER: the pack / unpack VALU work outweighs the bytes)
+_GQ_DT = torch.uint8 if _GQ == 2 else torch.bfloat16
 _dw_streams = {}
 
 
@@ -136,8 +138,8 @@ class SwinBlockFn(torch.autograd.Function):
         x_mid = K.gemm(0, ao, W16(a.proj.weight), M, C, C, bias=a.proj.bias.data, row_scale=dp_attn, rows_per_group=rpg,
                        residual=x)
         y2, mean2, rstd2 = K.layernorm_fwd(x_mid, M, C, blk.norm2.weight.data, blk.norm2.bias.data, 1e-5, want_stats=keep)
-        h_pre = torch.empty((M, 4 * C), dtype=bf16, device=x.device) if keep else None
-        h = K.gemm(0, y2, W16(mlp.fc1.weight), M, 4 * C, C, bias=mlp.fc1.bias.data, act=1, preact=h_pre, preact_is_grad=True)
+        h_pre = torch.empty((M, 4 * C), dtype=_GQ_DT, device=x.device) if keep else None      # GELU' (bf16, or the one-byte code with LAV_GELU_GRAD_U8=1)
+        h = K.gemm(0, y2, W16(mlp.fc1.weight), M, 4 * C, C, bias=mlp.fc1.bias.data, act=1, preact=h_pre, preact_is_grad=_GQ)
         out = K.gemm(0, h, W16(mlp.fc2.weight), M, C, 4 * C, bias=mlp.fc2.bias.data, row_scale=dp_mlp, rows_per_group=rpg,
                      residual=x_mid)
         if keep:
@@ -164,7 +166,7 @@ class SwinBlockFn(torch.autograd.Function):
         # --- MLP branch: out = x_mid + s * fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------
         dw_gemm(dy, h, C, 4 * C, M, out=G(mlp.fc2.weight), accumulate=True, k_keep=dp_mlp, k_rows_per_group=rpg,
                alpha=alpha if dp_mlp is not None else 1.0, splits=K.splits_for(C, 4 * C, M, dp_mlp is not None), rowsum_a=G(mlp.fc2.bias))
-        dh = K.gemm(0, dy, W16T(mlp.fc2.weight), M, 4 * C, C, gelu_in=h_pre, gelu_in_is_grad=True, row_scale=dp_mlp,
+        dh = K.gemm(0, dy, W16T(mlp.fc2.weight), M, 4 * C, C, gelu_in=h_pre, gelu_in_is_grad=_GQ, row_scale=dp_mlp,
                     rows_per_group=rpg, colsum=G(mlp.fc1.bias))
         dw_gemm(dh, y2, 4 * C, C, M, out=G(mlp.fc1.weight), accumulate=True, splits=K.splits_for(4 * C, C, M))
         d_y2 = K.gemm(0, dh, W16T(mlp.fc1.weight), M, C, 4 * C)
@@ -396,8 +398,8 @@ class BertLayerFn(torch.autograd.Function):
                                            want_stats=keep)
         inter, outp = layer.intermediate, layer.output
         F = inter.dense.weight.shape[0]
-        h_pre = torch.empty((R, F), dtype=bf16, device=x.device) if keep else None
-        h = K.gemm(0, x1, W16(inter.dense.weight), R, F, Hd, bias=inter.dense.bias.data, act=1, preact=h_pre, preact_is_grad=True)
+        h_pre = torch.empty((R, F), dtype=_GQ_DT, device=x.device) if keep else None
+        h = K.gemm(0, x1, W16(inter.dense.weight), R, F, Hd, bias=inter.dense.bias.data, act=1, preact=h_pre, preact_is_grad=_GQ)
         pre2 = K.gemm(0, h, W16(outp.dense.weight), R, Hd, F, bias=outp.dense.bias.data, dropout_p=p_hidden, seed=s2, residual=x1)
         y, mean2, rstd2 = K.layernorm_fwd(pre2, R, Hd, outp.LayerNorm.weight.data, outp.LayerNorm.bias.data, outp.LayerNorm.eps,
                                           want_stats=keep)
@@ -422,7 +424,7 @@ class BertLayerFn(torch.autograd.Function):
         d_pre2 = K.layernorm_bwd(dy, pre2, R, Hd, outp.LayerNorm.weight.data, mean2, rstd2, G(outp.LayerNorm.weight),
                                  G(outp.LayerNorm.bias), dx2=d_dense2, dropout_p=p, seed=s2, colsum=G(outp.dense.bias))
         dw_gemm(d_dense2, h, Hd, F, R, out=G(outp.dense.weight), accumulate=True, splits=K.splits_for(Hd, F, R))
-        dh = K.gemm(0, d_dense2, W16T(outp.dense.weight), R, F, Hd, gelu_in=h_pre, gelu_in_is_grad=True, colsum=G(inter.dense.bias))
+        dh = K.gemm(0, d_dense2, W16T(outp.dense.weight), R, F, Hd, gelu_in=h_pre, gelu_in_is_grad=_GQ, colsum=G(inter.dense.bias))
         dw_gemm(dh, x1, F, Hd, R, out=G(inter.dense.weight), accumulate=True, splits=K.splits_for(F, Hd, R))
         d_x1 = K.gemm(0, dh, W16T(inter.dense.weight), R, Hd, F, residual=d_pre2)
         del dh

@@ -216,6 +216,24 @@ def test_batched_weight_transpose_and_arena_copy():
     assert torch.equal(mod.fc.weight._lav16t, mod.fc.weight.bfloat16().t())
 
 
+def test_gemm_gelu_grad_one_byte_code():
+    """preact_is_grad = 2 / gelu_in_is_grad = 2: GELU'(z) stored as one byte per element (q = round((g + 0.25) * 256 / 1.5))."""
+    M, N, Kd = 512, 256, 128
+    X, W = rb(M, Kd), rb(N, Kd, seed=1, scale=0.2)
+    bias = torch.randn(N).cuda()
+    code = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+    y = K().gemm(0, X, W, M, N, Kd, bias=bias, act=1, preact=code, preact_is_grad=2)
+    z = (X.float() @ W.float().t() + bias).detach().requires_grad_(True)
+    yr = F.gelu(z)
+    yr.sum().backward()
+    close(y, yr, what="gelu output")
+    dec = code.float() * (1.5 / 256) - 0.25
+    assert (dec - z.grad).abs().max().item() < 0.004, (dec - z.grad).abs().max().item()
+    dY, W2 = rb(M, 64, seed=2), rb(64, N, seed=3, scale=0.2)           # dh = (dY W2^T^T) * gelu'
+    out = K().gemm(0, dY, W2.t().contiguous(), M, N, 64, gelu_in=code, gelu_in_is_grad=2)
+    close(out, (dY.float() @ W2.float()) * dec, what="multiply by the decoded GELU'")
+
+
 def test_gemm_ragged_vocab_tail():
     M, V, Kd = 64, 1018, 128                         # V % 8 == 2 like 30522
     ld = (V + 7) // 8 * 8
