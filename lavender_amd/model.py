@@ -160,6 +160,7 @@ class LAVENDER_Base(nn.Module):
     def _encode(self, feat, mask):
         """feat (n, L, H) bf16, mask (n, L) 0/1 -> last_hidden_state (n, L, H)."""
         arena = self.arena()
+        arena.sync_half_if_stale()                            # e.g. load_ckpt followed directly by a 'cross' call on cached features
         n, L, Hd = feat.shape
         km = mask.to(torch.int32).contiguous()
         x = feat.reshape(n * L, Hd)
