@@ -185,9 +185,13 @@ __global__ __launch_bounds__(512) void win_fwd_p(AttnArgs a, int bsplit) {
 // NW = 4: one wave per SIMD, two query tiles per wave (512 registers each).  NW = 8: two waves per SIMD, ONE query tile
 // per wave (<= 256 registers: 128 for the resident dS sums), so the MFMA -> VALU -> MFMA chains of one wave are
 // covered by the other; the two wave groups flush into the same four LDS tables one after the other.
+#ifndef WIN_DQ_NOPREFETCH
+#define WIN_DQ_NOPREFETCH 1
+#endif
 template <bool DBIAS, int NW>
 __global__ __launch_bounds__(NW * 64) void win_dq_p(AttnArgs a, int bsplit, float* delta_out) {
     constexpr int NQ = 8 / NW;                           // query tiles per wave
+    constexpr bool PREFETCH = NW == 4 && !(DBIAS && WIN_DQ_NOPREFETCH);
     constexpr int NTHR = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][K(A) 16K | K(tr) 16K | V(A) 16K] + kcode + 4 x dtbl
     WinGeo g;
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(NW * 64) void win_dq_p(AttnArgs a, int bsplit, floa
         const char* Ks = smem + cur * 49152;
         const char* Kv = Ks + 16384;
         const char* Vs = Ks + 32768;
-        if (NW == 8 && b > g.b0) load(b);
+        if (!PREFETCH && b > g.b0) load(b);
         bf16x8 qf[NQ][2], dof[NQ][2];
         float dl[NQ], lse[NQ];
 #pragma unroll
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(NW * 64) void win_dq_p(AttnArgs a, int bsplit, floa
         }
         if (b + 1 < g.b1) {
             issue_kv(b + 1, cur ^ 1);
-            if (NW == 4) load(b + 1);                     // NW == 8: no register prefetch (the second wave of the SIMD covers the latency)
+            if (PREFETCH) load(b + 1);                    // register prefetch of the next window's q / dO / O rows
         }
 
 #pragma unroll
