@@ -170,3 +170,13 @@ def test_args_json_overlay(tmp_path):
     cfg.write_text(json.dumps({"size_batch": 24, "size_frame": 4, "type": "pretrain", "lr": 2e-5}))
     a = parse_with_config(["--config", str(cfg), "--size_batch", "32"])
     assert a.size_batch == 32 and a.size_frame == 4 and a.type == "pretrain" and a.lr == 2e-5   # CLI > JSON > default
+
+
+def test_bench_algorithmic_flops_match_the_survey_table():
+    """bench.flops_per_sample is the closed form of SURVEY.md section 8d; its table gives 428.9 / 80.7 / 1956.0 / 574.6
+    GFLOP forward per sample for configs 2, 1, 4 and 5 -- the figure roofline / step_mfma_frac are computed from."""
+    import bench as B
+    assert abs(B.flops_per_sample() / 1e9 - 428.9) < 0.1
+    assert abs(B.flops_per_sample(E=96, depths=(2, 2, 6, 2), layers=2, n_seq=3) / 1e9 - 80.7) < 0.1
+    assert abs(B.flops_per_sample(E=192, win=(8, 12, 12), S=384) / 1e9 - 1956.0) < 0.1
+    assert abs(B.flops_per_sample(X=26, n_seq=8) / 1e9 - 574.6) < 0.1
