@@ -342,3 +342,42 @@ def test_weight_gradient_side_stream_is_race_free():
             assert ((got_all - ref_all).norm() / ref_all.norm()).item() < 1e-4      # the rest: atomics, order-dependent rounding
     finally:
         E._DW_SIDE = keep
+
+
+def test_load_ckpt_refreshes_the_working_copies(tmp_path):
+    """load_ckpt on a model that already lives in a ParamArena: fp32 master, bf16 copy and the transposed copy all follow
+    (forward AND backward then match the model the checkpoint came from)."""
+    from tests.helpers import Tok, make_args
+    import lavender_amd as LA
+    from lavender_amd.dist import set_seed
+    B = 2
+    b = make_batch(B, vocab=BERT_CFGS["micro"]["vocab"])
+    lab = torch.full((B, 32), -1, dtype=torch.long)
+    lab[:, 3] = 1500
+
+    def run(m):
+        m.eval()
+        m.arena().zero_grad()
+        np.random.seed(1)
+        out = m({"img": b["img"].cuda(), "txt": b["txt"].cuda(), "mask": b["mask"].cuda(), "ans_mtm": lab.cuda()})
+        logits = out["out_mtm"].float().clone()
+        ls = LA.CrossEntropyIgnore()(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten(), B)
+        ls.backward()
+        torch.cuda.synchronize()
+        return logits, m.arena().grad.clone()
+
+    set_seed(1)
+    a = LA.LAVENDER_Pretrain_MLM(make_args("micro", "micro", B), Tok()).cuda()
+    a.arena()
+    path = str(tmp_path / "ck.pt")
+    torch.save({k: v.cpu() for k, v in a.state_dict().items()}, path)
+    set_seed(2)
+    c = LA.LAVENDER_Pretrain_MLM(make_args("micro", "micro", B), Tok()).cuda()
+    c.arena()
+    la, ga = run(a)
+    l0, _ = run(c)
+    assert (l0 - la).abs().max() > 1e-2                       # different weights before the load
+    c.load_ckpt(path)
+    lc, gc = run(c)
+    assert torch.equal(lc, la)
+    assert ((gc - ga).norm() / ga.norm()).item() < 1e-4       # atomics in the small-vector gradients: order-dependent rounding

@@ -180,3 +180,29 @@ def test_bench_algorithmic_flops_match_the_survey_table():
     assert abs(B.flops_per_sample(E=96, depths=(2, 2, 6, 2), layers=2, n_seq=3) / 1e9 - 80.7) < 0.1
     assert abs(B.flops_per_sample(E=192, win=(8, 12, 12), S=384) / 1e9 - 1956.0) < 0.1
     assert abs(B.flops_per_sample(X=26, n_seq=8) / 1e9 - 574.6) < 0.1
+
+
+def test_checkpoint_contract_round_trip(tmp_path):
+    """LAVENDER_Base.load_ckpt (model.py:352-429): a state_dict written the way Agent_Base.save_model writes it loads back
+    key for key; foreign task-head keys and missing heads are tolerated (non-strict), a missing file is a no-op."""
+    import torch
+    from tests.helpers import Tok, make_args
+    from lavender_amd import LAVENDER_Pretrain_MLM, LAVENDER_Pretrain
+    torch.manual_seed(1)
+    a = LAVENDER_Pretrain_MLM(make_args("micro", "micro", 2), Tok())
+    path = str(tmp_path / "ckpt_violet_pretrain_1.pt")
+    torch.save({k: v.cpu() for k, v in a.state_dict().items()}, path)
+    torch.manual_seed(2)
+    b = LAVENDER_Pretrain_MLM(make_args("micro", "micro", 2), Tok())
+    assert not torch.equal(a.enc_img.swin.layers[0].blocks[0].mlp.fc1.weight, b.enc_img.swin.layers[0].blocks[0].mlp.fc1.weight)
+    b.load_ckpt(path)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k], sb[k]) for k in sa)
+    # the pre-trained MLM checkpoint into the task-specific model: its score head stays at init, emb_task is unexpected
+    torch.manual_seed(3)
+    c = LAVENDER_Pretrain(make_args("micro", "micro", 2), Tok())
+    fc0 = c.fc[1].weight.detach().clone()
+    c.load_ckpt(path)
+    assert torch.equal(c.fc[1].weight, fc0) and torch.equal(c.trsfr.layer[0].output.dense.weight, a.trsfr.layer[0].output.dense.weight)
+    c.load_ckpt(str(tmp_path / "does_not_exist.pt"))
+    c.load_ckpt('')
