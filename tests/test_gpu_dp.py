@@ -89,3 +89,53 @@ def test_two_ranks_allreduce_and_replica_consistency():
     assert rel0 < 2e-2 and rel1 < 2e-2, (rel0, rel1)            # sum of per-rank grads (atomics: order-dependent fp32 rounding)
     assert w0a == w1a                                            # broadcast from rank 0
     assert w0b == w1b and w0b != w0a                             # identical update on both replicas
+
+
+def _rccl_worker(port, q):
+    """One rank over the REAL backend ("nccl" = RCCL): exercises the reducer's stream / async-work handling against RCCL
+    itself (the two-rank test above has to use gloo because RCCL wants one device per rank)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import lavender_amd as LA
+    from lavender_amd.dp import ArenaReducer
+    from tests.helpers import Tok, make_args
+    torch.manual_seed(7)
+    m = LA.LAVENDER_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3), Tok()).cuda()
+    m.arena()
+    agent = LA.Agent_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3), m)
+    g_ref = _rank_grads(0, agent, m)                       # no reducer attached
+    agent.dp = ArenaReducer(m)                             # prepare_dist_model() only attaches it for world > 1
+    early = list(agent.dp.early_ranges) + list(agent.dp.stage_ranges.values())
+    _rank_grads(0, agent, m)
+    done_early = sorted(agent.dp._done)
+    agent.dp.finish()
+    torch.cuda.synchronize()
+    g = m.arena().grad.clone()
+    ok = bool(((g - g_ref).norm() / g_ref.norm()).item() < 1e-4) and sorted(early) == done_early and agent.dp._done == []
+    agent.optzr.step(max_norm=1.0, grad_div=1.0)
+    torch.cuda.synchronize()
+    q.put(ok)
+    dist.destroy_process_group()
+
+
+def test_reducer_over_rccl_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29700 + (os.getpid() % 1000), q))
+    p.start()
+    import queue as _queue
+    import time as _time
+    t0, res = _time.time(), None
+    while res is None:
+        try:
+            res = q.get(timeout=2)
+        except _queue.Empty:
+            if p.exitcode not in (None, 0) or _time.time() - t0 > 240:
+                if p.is_alive():
+                    p.terminate()
+                pytest.fail(f"RCCL worker failed (exit code {p.exitcode})")
+    p.join(timeout=60)
+    assert res is True
