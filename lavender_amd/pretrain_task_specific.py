@@ -62,12 +62,13 @@ class LAVENDER_Pretrain(LAVENDER_Base):
         Lv = (1 + _h * _w) * _T
 
         feat_img, mask_img, feat_txt, mask_txt = self.go_feat(img, txt, mask)
-        out, _ = self.go_cross(feat_img, mask_img, feat_txt, mask_txt)
-        out_mtm = self.fc_mtm(out[:, Lv:])
-
+        # the B true pairs (MLM head) and the B*O matching pairs (score head) go through the fusion encoder as one batch
+        # (the reference runs it twice, :147 and :165); same arithmetic per sequence, half the launches
         vi, ti, _ = vtm_pairs(_B, _O)
-        out, _ = self.go_cross_pairs(feat_img, mask_img, feat_txt, mask_txt, vi, ti)
-        out_vtm = self.fc(out[:, Lv, :], O=_O, temp=self.args.temp)
+        out, _ = self.go_cross_pairs(feat_img, mask_img, feat_txt, mask_txt, np.concatenate([np.arange(_B), vi]),
+                                     np.concatenate([np.arange(_B), ti]))
+        out_mtm = self.fc_mtm(out[:_B, Lv:])
+        out_vtm = self.fc(out[_B:, Lv, :], O=_O, temp=self.args.temp)
         ans_vtm = torch.zeros(_B, dtype=torch.long, device=txt.device)
         return {"out_vtm": out_vtm, "out_mtm": out_mtm, "ans_vtm": ans_vtm, "ans_mtm": ans_mtm}
 
