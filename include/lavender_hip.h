@@ -68,6 +68,8 @@ typedef struct lav_gemm_epilogue {
     int preact_is_grad;       /* forward: store act'(z) instead of z (the backward then needs one multiply, no erf); 2 = GELU only,
                                  as ONE BYTE per element: q = round((g + 0.25) * 256 / 1.5), preact is uint8 [M, ldp] */
     int gelu_in_is_grad;      /* backward: gelu_in already holds GELU'(z) (1: bf16, 2: the one-byte code above, ldg in bytes) */
+    int residual_f32;         /* residual is fp32 [M, ldr] (the fp32 residual stream of the post-LN fusion encoder:
+                                 pre = x + dropout(dense(.)) is then stored fp32 with out_mode 1) */
 } lav_gemm_epilogue;
 
 int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
@@ -87,8 +89,17 @@ typedef struct lav_ln_gather {
     int H, W, C0;             /* source token grid (per frame) and channel count, mode 1 */
 } lav_ln_gather;
 
+/* Optional fp32 side of the LayerNorm I/O (NULL = all-bf16): the fusion encoder keeps its residual stream in fp32 --
+ * the pre-LN sums are fp32 GEMM outputs (x_f32 = 1) and the normalised rows are written twice, bf16 for the next GEMM's
+ * operand and fp32 (y32) for the next residual add.  y (bf16) may be NULL when only the fp32 copy is wanted. */
+typedef struct lav_ln_f32 {
+    int x_f32;                /* x is fp32 [rows, ldx] */
+    void* y32; long ldy32;    /* fp32 copy of the output, or NULL */
+} lav_ln_f32;
+
 int lav_layernorm_fwd(void* stream, int rows, int C, const void* x, long ldx, const lav_ln_gather* gather,
-                      const float* gamma, const float* beta, float eps, void* y, long ldy, float* mean, float* rstd);
+                      const float* gamma, const float* beta, float eps, void* y, long ldy, float* mean, float* rstd,
+                      const lav_ln_f32* f32io);
 
 /* Backward.  dx = LNbwd(dy) [+ add_in]  (add_in: the residual-branch gradient, bf16, same layout as dx).
  * dgamma/dbeta (fp32 [C]) are accumulated atomically.  With gather.mode==1 dx is scattered back to the
@@ -102,6 +113,7 @@ typedef struct lav_ln_bwd_extra {
     const float* row_scale; int rows_per_group;
     float dropout_p; uint32_t seed;
     float* colsum;
+    int x_f32;                /* the saved LayerNorm input x is fp32 (see lav_ln_f32) */
 } lav_ln_bwd_extra;
 
 int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, long lddy, const void* x, long ldx,
@@ -255,6 +267,30 @@ int lav_transpose_bf16_batched(void* stream, int n_mats, const lav_mat_desc* des
                                void* dst_bf16);
 int lav_cast_f32_to_bf16(void* stream, long n, const float* in, void* out);
 int lav_fill_droppath(void* stream, int n_blocks, int B, const float* keep_prob, uint32_t seed, float* scale);
+
+/* ---------------------------------------------------------------------------------------------
+ * fp32-I/O VALIDATION mode (SURVEY.md section 8c tier T2; north_star "MLM logits within 1e-3 of reference"): the forward
+ * path with fp32 activations end to end.  Forward only, eval arithmetic, speed irrelevant.  LayerNorm uses
+ * lav_layernorm_fwd with lav_ln_f32 {x_f32 = 1, y32}.
+ *   lav_v_gemm_f32       every nn.Linear of the path (same call sites as lav_gemm_bf16) on v_mfma_f32_32x32x2_f32 (exact fp32):
+ *                        C[M,N] = act(A[M,K] . B[N,K]^T + bias) + residual; act 0 none, 1 erf-GELU, 2 ReLU
+ *   lav_v_attention_f32  window / sequence attention of lav_attention_fwd for ANY geometry, including token grids that
+ *                        are not window multiples: the zero-pad branch of video_swin.py:211-215,241-242 (padding is applied
+ *                        after norm1, so a padded token's q/k/v is the qkv bias = pad_qkv[3C]); qkv fp32 (tokens, 3C), out fp32
+ *   lav_v_im2col_f32     lav_patch_im2col with fp32 rows
+ *   lav_v_video_embed_f32 / lav_v_text_embed_f32   lav_video_embed_fwd / lav_text_embed_fwd (no dropout) with fp32 I/O
+ *   lav_v_gather_rows_f32 lav_gather_rows on fp32 rows */
+int lav_v_gemm_f32(void* stream, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                   const float* bias, int act, const float* residual, long ldr);
+int lav_v_attention_f32(void* stream, const lav_attn_desc* d, const float* qkv, float* out, const float* pad_qkv);
+int lav_v_im2col_f32(void* stream, const float* img, int B, int T, int H, int W, int frame_major, float* out);
+int lav_v_video_embed_f32(void* stream, int B, int T, int hw, int Hd, const float* feat, const float* emb_cls,
+                          const float* emb_pos, const float* emb_len, const float* gamma, const float* beta, float eps,
+                          float* out, long seq_rows);
+int lav_v_text_embed_f32(void* stream, int n, int X, int Hd, const int64_t* ids, const float* word, const float* pos,
+                         const float* type0, const float* gamma, const float* beta, float eps, float* out);
+int lav_v_gather_rows_f32(void* stream, int n_rows, int C, const float* src, long lds_, const int32_t* src_row, float* dst,
+                          long ldd);
 
 #ifdef __cplusplus
 }

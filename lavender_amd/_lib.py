@@ -28,7 +28,8 @@ class GemmEpilogue(C.Structure):
     _fields_ = [("bias", vp), ("act", i32), ("preact", vp), ("ldp", i64), ("gelu_in", vp), ("ldg", i64),
                 ("dropout_p", f32), ("seed", u32), ("row_scale", vp), ("rows_per_group", i32), ("residual", vp),
                 ("ldr", i64), ("colsum", vp), ("alpha", f32), ("out_mode", i32), ("k_keep", vp),
-                ("k_rows_per_group", i32), ("rowsum_a", vp), ("preact_is_grad", i32), ("gelu_in_is_grad", i32)]
+                ("k_rows_per_group", i32), ("rowsum_a", vp), ("preact_is_grad", i32), ("gelu_in_is_grad", i32),
+                ("residual_f32", i32)]
 
 
 class LnGather(C.Structure):
@@ -37,7 +38,11 @@ class LnGather(C.Structure):
 
 class LnBwdExtra(C.Structure):
     _fields_ = [("dx2", vp), ("lddx2", i64), ("row_scale", vp), ("rows_per_group", i32), ("dropout_p", f32),
-                ("seed", u32), ("colsum", vp)]
+                ("seed", u32), ("colsum", vp), ("x_f32", i32)]
+
+
+class LnF32(C.Structure):
+    _fields_ = [("x_f32", i32), ("y32", vp), ("ldy32", i64)]
 
 
 class AttnDesc(C.Structure):
@@ -53,7 +58,7 @@ _SIGS = {
     "lav_last_error": (C.c_char_p, []),
     "lav_abi_version": (i32, []),
     "lav_gemm_bf16": (i32, [vp, i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, P(GemmEpilogue), i32]),
-    "lav_layernorm_fwd": (i32, [vp, i32, i32, vp, i64, P(LnGather), vp, vp, f32, vp, i64, vp, vp]),
+    "lav_layernorm_fwd": (i32, [vp, i32, i32, vp, i64, P(LnGather), vp, vp, f32, vp, i64, vp, vp, P(LnF32)]),
     "lav_layernorm_bwd": (i32, [vp, i32, i32, vp, i64, vp, i64, P(LnGather), vp, vp, vp, vp, i64, vp, i64, vp, vp,
                                 P(LnBwdExtra)]),
     "lav_scale_mask_rows": (i32, [vp, i32, i32, vp, i64, vp, i64, vp, i32, f32, u32, vp, vp, i64]),
@@ -79,6 +84,13 @@ _SIGS = {
     "lav_adamw_step": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, P(f32), P(f32), f32, f32, f32, i32, vp, f32, f32]),
     "lav_cast_f32_to_bf16": (i32, [vp, i64, vp, vp]),
     "lav_fill_droppath": (i32, [vp, i32, i32, vp, u32, vp]),
+    # fp32-I/O validation mode (csrc/validate.hip)
+    "lav_v_gemm_f32": (i32, [vp, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, vp, i64]),
+    "lav_v_attention_f32": (i32, [vp, P(AttnDesc), vp, vp, vp]),
+    "lav_v_im2col_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "lav_v_video_embed_f32": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, i64]),
+    "lav_v_text_embed_f32": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp]),
+    "lav_v_gather_rows_f32": (i32, [vp, i32, i32, vp, i64, vp, vp, i64]),
 }
 class MatDesc(C.Structure):                  # struct lav_mat_desc
     _fields_ = [("src_off", C.c_long), ("dst_off", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("ld_dst", C.c_int),

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void win_dq_p(AttnArgs a, int bsplit, floa
     if (DBIAS) for (int r = tid; r < 4 * a.tbl_rows; r += NTHR) dtbl_all[r] = 0.f;
     if (tid < 256) {
         const int i = tid;
-        kcode[i] = i < N ? (i / (a.d.ww * a.d.wh)) * a.cstride_d + ((i / a.d.ww) % a.d.wh) * a.cstride_h + (i % a.d.ww) : 0;
+        kcode[i] = i < N ? (i / (a.d.cfg_ww * a.d.cfg_wh)) * a.cstride_d + ((i / a.d.cfg_ww) % a.d.cfg_wh) * a.cstride_h + (i % a.d.cfg_ww) : 0;
         const int rel = a.d.tok_table[g.ws * 256 + i];
         srel_l[i] = rel < 0 ? 0 : rel;      // padded keys read a valid row: their scores are masked to -inf-like by the bias table
     }
@@ -567,8 +567,9 @@ __global__ __launch_bounds__(256) void build_bias_kernel(AttnArgs a, bf16_t* com
             if (k >= a.N) v = -30000.f;
             else if (q >= a.N) v = 0.f;
             else {
-                const int qw = q % d.ww, qh = (q / d.ww) % d.wh, qd = q / (d.ww * d.wh);
-                const int kw = k % d.ww, kh = (k / d.ww) % d.wh, kd = k / (d.ww * d.wh);
+                // index decode with the CONFIGURED (h, w) extents: relative_position_index[:N, :N] (video_swin.py:153)
+                const int qw = q % d.cfg_ww, qh = (q / d.cfg_ww) % d.cfg_wh, qd = q / (d.cfg_ww * d.cfg_wh);
+                const int kw = k % d.cfg_ww, kh = (k / d.cfg_ww) % d.cfg_wh, kd = k / (d.cfg_ww * d.cfg_wh);
                 const int bi = (qd - kd) * a.cstride_d + (qh - kh) * a.cstride_h + (qw - kw) + a.tbl_const;
                 v = d.bias_table[(long)bi * d.heads + head];
                 if (d.type_region[type * 256 + q] != d.type_region[type * 256 + k]) v += -100.0f;

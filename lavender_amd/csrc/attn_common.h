@@ -60,7 +60,9 @@ __device__ __forceinline__ TokInfo win_token(const AttnArgs& a, int win, int i) 
     if (sw_ >= d.W) sw_ -= d.W;
     TokInfo o;
     o.row = ((b * d.D + sd_) * d.H + sh_) * d.W + sw_;
-    o.code = di * a.cstride_d + hi * a.cstride_h + wi;
+    // relative_position_index[:N, :N] of the CONFIGURED window (video_swin.py:153): index i is decoded with the configured
+    // (h, w) extents -- identical to (di, hi, wi) unless the spatial window is clamped
+    o.code = (i / (d.cfg_wh * d.cfg_ww)) * a.cstride_d + ((i / d.cfg_ww) % d.cfg_wh) * a.cstride_h + (i % d.cfg_ww);
     int rd = d.sd ? (pd >= d.D - d.wd) + (pd >= d.D - d.sd) : 0;
     int rh = d.sh ? (ph >= d.H - d.wh) + (ph >= d.H - d.sh) : 0;
     int rw = d.sw ? (pw >= d.W - d.ww) + (pw >= d.W - d.sw) : 0;

@@ -143,6 +143,7 @@ __device__ __forceinline__ bf16x8 frag_read(const char* lds, int t16, int ks, in
 // training step uses, so that each runs straight-line code (the all-features version is ~600 basic blocks of
 // uniform branches and costs more than the k-loop on the short-K GEMMs of this model).
 enum : unsigned { EF_BIAS = 1, EF_ACT = 2, EF_GIN = 4, EF_DROP = 8, EF_RSCALE = 16, EF_RES = 32, EF_COLSUM = 64,
+                  EF_O32 = 128,        // fp32 store (the fp32 residual stream of the fusion encoder); the residual's own type is a run-time flag
                   EF_TNFLUSH = 0x4000, EF_GENERIC = 0x8000, EF_ALL = 0xFFFF };
 
 // CH = 16-byte chunks per staged row (16: a 128-column block-wide tile; 8: a 64-column tile private to ONE wave -- then
@@ -210,11 +211,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
     static_assert(NIT % GRP == 0, "epilogue row grouping");  // issued back-to-back so HBM latency is paid once per group
 #pragma unroll 1
     for (int j0 = 0; j0 < NIT; j0 += GRP) {
-        uint4 pre_g[GRP], pre_r[GRP];
+        uint4 pre_g[GRP], pre_r[GRP], pre_r2[GRP];
 #pragma unroll
         for (int u = 0; u < GRP; ++u) {
             const int grow = m0 + etid / CH + RPP * (j0 + u);
-            pre_g[u] = make_uint4(0, 0, 0, 0); pre_r[u] = pre_g[u];
+            pre_g[u] = make_uint4(0, 0, 0, 0); pre_r[u] = pre_g[u]; pre_r2[u] = pre_g[u];
             if (inside && grow < g.M) {
                 if (has_gin) {
                     if (e.gelu_in_is_grad == 2) {                 // one byte per element (see gq_pack8)
@@ -224,7 +225,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
                         pre_g[u] = *(const uint4*)((const bf16_t*)e.gelu_in + (long)grow * e.ldg + gcol);
                     }
                 }
-                if (has_res) pre_r[u] = *(const uint4*)((const bf16_t*)e.residual + (long)grow * e.ldr + gcol);
+                if (has_res) {
+                    if (e.residual_f32) {
+                        const float* rp = (const float*)e.residual + (long)grow * e.ldr + gcol;
+                        pre_r[u] = *(const uint4*)rp; pre_r2[u] = *(const uint4*)(rp + 4);
+                    } else {
+                        pre_r[u] = *(const uint4*)((const bf16_t*)e.residual + (long)grow * e.ldr + gcol);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -307,7 +315,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         if (has_res) {
             const bf16_t* p = (const bf16_t*)e.residual + (long)grow * e.ldr + gcol;
             float h[8];
-            if (full) unpack8(pre_r[u], h);
+            if (e.residual_f32) {
+                if (full) { *(uint4*)&h[0] = pre_r[u]; *(uint4*)&h[4] = pre_r2[u]; }
+                else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? ((const float*)e.residual)[(long)grow * e.ldr + gcol + x] : 0.f;
+            } else if (full) unpack8(pre_r[u], h);
             else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? bf2f(p[x]) : 0.f;
 #pragma unroll
             for (int x = 0; x < 8; ++x) v[x] += h[x];
@@ -322,11 +333,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             float* p = g.ws + ((long)split * g.ws_tiles + (long)(m0 / ROWS) * ((g.N + BN - 1) / BN) + n0 / BN) * (ROWS * BN)
                        + row * BN + cc * 8;
             *(float4*)p = *(float4*)&v[0]; *(float4*)(p + 4) = *(float4*)&v[4];
-        } else if (!GEN || e.out_mode == 0) {
+        } else if (GEN ? e.out_mode == 0 : !(F & EF_O32)) {
             bf16_t* p = (bf16_t*)g.C + (long)grow * g.ldc + gcol;
             if (full) *(uint4*)p = pack8(v);
             else for (int x = 0; x < ncols; ++x) p[x] = f2bf(v[x]);
-        } else if (e.out_mode == 1) {
+        } else if (!GEN || e.out_mode == 1) {
             float* p = (float*)g.C + (long)grow * g.ldc + gcol;
             if (full) { *(float4*)p = *(float4*)&v[0]; *(float4*)(p + 4) = *(float4*)&v[4]; }
             else for (int x = 0; x < ncols; ++x) p[x] = v[x];
@@ -1027,10 +1038,12 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     if (g.e.row_scale) fm |= EF_RSCALE;
     if (g.e.residual) fm |= EF_RES;
     if (g.e.colsum) fm |= EF_COLSUM;
-    if (g.e.out_mode != 0 || (N % 8) != 0) fm |= EF_GENERIC;
+    if (g.e.out_mode == 1) fm |= EF_O32;
+    if (g.e.out_mode == 2 || (N % 8) != 0) fm |= EF_GENERIC;
     constexpr unsigned S_B = EF_BIAS, S_BG = EF_BIAS | EF_ACT, S_GC = EF_GIN | EF_RSCALE | EF_COLSUM,
-                       S_BDR = EF_BIAS | EF_DROP | EF_RSCALE | EF_RES;
-    const unsigned fsel = !(fm & ~S_B) ? S_B : !(fm & ~S_BG) ? S_BG : !(fm & ~S_GC) ? S_GC : !(fm & ~S_BDR) ? S_BDR : EF_ALL;
+                       S_BDR = EF_BIAS | EF_DROP | EF_RSCALE | EF_RES, S_BDRO = S_BDR | EF_O32;
+    const unsigned fsel = !(fm & ~S_B) ? S_B : !(fm & ~S_BG) ? S_BG : !(fm & ~S_GC) ? S_GC : !(fm & ~S_BDR) ? S_BDR :
+                          ((fm & EF_O32) && !(fm & ~S_BDRO)) ? S_BDRO : EF_ALL;
     constexpr int lav_threads_gemm_huge_kernel = 512, lav_threads_gemm_big_kernel = 512;
     (void)lav_threads_gemm_huge_kernel; (void)lav_threads_gemm_big_kernel;
 #define LAV_LAUNCH_ONE(KERN, AKC_, BKC_, F_, GRID, LDS)                                                                   \
@@ -1054,6 +1067,7 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         else if (fsel == S_BG) LAV_LAUNCH_BY_LAYOUT(KERN, S_BG, GRID, LDS);                                               \
         else if (fsel == S_GC) LAV_LAUNCH_BY_LAYOUT(KERN, S_GC, GRID, LDS);                                               \
         else if (fsel == S_BDR) LAV_LAUNCH_BY_LAYOUT(KERN, S_BDR, GRID, LDS);                                             \
+        else if (fsel == S_BDRO) LAV_LAUNCH_BY_LAYOUT(KERN, S_BDRO, GRID, LDS);                                           \
         else LAV_LAUNCH_BY_LAYOUT(KERN, EF_ALL, GRID, LDS);                                                               \
     } while (0)
     // pick the tile by estimated machine fill: tiles / (rounds * resident slots), weighted by the tile's own efficiency

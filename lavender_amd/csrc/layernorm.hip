@@ -27,11 +27,22 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-template <int G, int ITERS>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int C, const bf16_t* __restrict__ x, long ldx, LnGeom geo,
+// 8 consecutive elements of a bf16 or fp32 row
+template <bool F32>
+__device__ __forceinline__ void load8(const void* base, long off, float* v) {
+    if (F32) {
+        const float* p = (const float*)base + off;
+        *(float4*)&v[0] = *(const float4*)p; *(float4*)&v[4] = *(const float4*)(p + 4);
+    } else {
+        unpack8(*(const uint4*)((const bf16_t*)base + off), v);
+    }
+}
+
+template <int G, int ITERS, bool X32>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int C, const void* __restrict__ x, long ldx, LnGeom geo,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     float eps, bf16_t* __restrict__ y, long ldy, float* mean_out,
-                                                    float* rstd_out) {
+                                                    float* rstd_out, float* __restrict__ y32, long ldy32) {
     const int tid = threadIdx.x, gl = tid % G;
     const int row = blockIdx.x * (256 / G) + tid / G;
     if (row >= rows) return;
@@ -41,8 +52,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int C, const bf16
     for (int it = 0; it < ITERS; ++it) {
         int col = (it * G + gl) * 8;
         if (col < C) {
-            uint4 u = *(const uint4*)(x + ln_src_off(geo, row, col, ldx));
-            unpack8(u, v[it]);
+            load8<X32>(x, ln_src_off(geo, row, col, ldx), v[it]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += v[it][k];
         } else {
@@ -72,7 +82,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int C, const bf16
             const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = (v[it][k] - mean) * rstd * gg[k] + bb[k];
-            *(uint4*)(y + (long)row * ldy + col) = pack8(o);
+            if (y) *(uint4*)(y + (long)row * ldy + col) = pack8(o);
+            if (y32) {
+                float* q32 = y32 + (long)row * ldy32 + col;
+                *(float4*)q32 = *(const float4*)&o[0]; *(float4*)(q32 + 4) = *(const float4*)&o[4];
+            }
         }
     }
     if (gl == 0) {
@@ -84,7 +98,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int C, const bf16
 struct LnBwdArgs {
     int rows, C;
     const bf16_t* dy; long lddy;
-    const bf16_t* x; long ldx;
+    const void* x; long ldx;
     LnGeom geo;
     const float* gamma; const float* mean; const float* rstd;
     const bf16_t* add_in; long ldadd;
@@ -94,7 +108,7 @@ struct LnBwdArgs {
     uint32_t thresh;
 };
 
-template <int G, int ITERS>
+template <int G, int ITERS, bool X32>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     extern __shared__ float red[];                          // [256/G][C]
     const int tid = threadIdx.x, gl = tid % G, grp = tid / G;
@@ -111,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     constexpr int NR = ITERS == 1 ? 2 : 1;                   // wider rows (C > 512) already carry two 16-byte chunks per lane per tensor
     const int rstride = gridDim.x * RPW;
     for (int row0 = blockIdx.x * RPW + grp; row0 < a.rows; row0 += NR * rstride) {
-        uint4 xu[NR][ITERS], du[NR][ITERS], au[NR][ITERS];
+        uint4 xu[NR][ITERS], xu2[NR][ITERS], du[NR][ITERS], au[NR][ITERS];
         float mean[NR], rstd[NR];
         bool live[NR];
 #pragma unroll
@@ -123,9 +137,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 const int col = (it * G + gl) * 8;
-                xu[q][it] = make_uint4(0, 0, 0, 0); du[q][it] = xu[q][it]; au[q][it] = xu[q][it];
+                xu[q][it] = make_uint4(0, 0, 0, 0); du[q][it] = xu[q][it]; au[q][it] = xu[q][it]; xu2[q][it] = xu[q][it];
                 if (live[q] && col < a.C) {
-                    xu[q][it] = *(const uint4*)(a.x + ln_src_off(a.geo, row, col, a.ldx));
+                    if (X32) {
+                        const float* xp = (const float*)a.x + ln_src_off(a.geo, row, col, a.ldx);
+                        xu[q][it] = *(const uint4*)xp; xu2[q][it] = *(const uint4*)(xp + 4);
+                    } else {
+                        xu[q][it] = *(const uint4*)((const bf16_t*)a.x + ln_src_off(a.geo, row, col, a.ldx));
+                    }
                     du[q][it] = *(const uint4*)(a.dy + (long)row * a.lddy + col);
                     if (a.add_in) au[q][it] = *(const uint4*)(a.add_in + ln_src_off(a.geo, row, col, a.ldadd));
                 }
@@ -142,7 +161,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
                 const int col = (it * G + gl) * 8;
                 if (col < a.C) {
                     float xv[8], dv[8];
-                    unpack8(xu[q][it], xv);
+                    if (X32) { *(uint4*)&xv[0] = xu[q][it]; *(uint4*)&xv[4] = xu2[q][it]; }
+                    else unpack8(xu[q][it], xv);
                     unpack8(du[q][it], dv);
                     float4 g0 = *(const float4*)(a.gamma + col), g1 = *(const float4*)(a.gamma + col + 4);
                     const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -222,15 +242,17 @@ static inline void pick_geom(int C, int& G, int& iters) {
     iters = (C + G * 8 - 1) / (G * 8);
 }
 
-#define LN_DISPATCH(KERNEL, ...)                                                         \
-    if (G == 16) { KERNEL(16, 1) }                                                       \
-    else if (G == 32) { KERNEL(32, 1) }                                                  \
-    else if (iters == 1) { KERNEL(64, 1) }                                               \
-    else if (iters == 2) { KERNEL(64, 2) }                                               \
-    else if (iters == 3) { KERNEL(64, 3) }                                               \
-    else if (iters == 4) { KERNEL(64, 4) }                                               \
-    else if (iters <= 6) { KERNEL(64, 6) }                                               \
+#define LN_DISPATCH_T(KERNEL, X32_)                                                      \
+    if (G == 16) { KERNEL(16, 1, X32_) }                                                 \
+    else if (G == 32) { KERNEL(32, 1, X32_) }                                            \
+    else if (iters == 1) { KERNEL(64, 1, X32_) }                                         \
+    else if (iters == 2) { KERNEL(64, 2, X32_) }                                         \
+    else if (iters == 3) { KERNEL(64, 3, X32_) }                                         \
+    else if (iters == 4) { KERNEL(64, 4, X32_) }                                         \
+    else if (iters <= 6) { KERNEL(64, 6, X32_) }                                         \
     else { lav_set_error("layernorm: C=%d too wide (max 3072)", C); return LAV_E_UNSUPPORTED; }
+#define LN_DISPATCH(KERNEL, x32)                                                         \
+    if (x32) { LN_DISPATCH_T(KERNEL, true) } else { LN_DISPATCH_T(KERNEL, false) }
 
 static int check_gather(const lav_ln_gather* g, int C, LnGeom& geo) {
     geo.mode = 0; geo.H = geo.W = geo.C0 = 0;
@@ -244,19 +266,22 @@ static int check_gather(const lav_ln_gather* g, int C, LnGeom& geo) {
 
 extern "C" int lav_layernorm_fwd(void* stream, int rows, int C, const void* x, long ldx, const lav_ln_gather* gather,
                                  const float* gamma, const float* beta, float eps, void* y, long ldy, float* mean,
-                                 float* rstd) {
+                                 float* rstd, const lav_ln_f32* f32io) {
     LAV_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "lav_layernorm_fwd: rows=%d C=%d (C must be a multiple of 8)", rows, C);
-    LAV_REQUIRE(x && y && gamma && beta, "lav_layernorm_fwd: null pointer");
-    LAV_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "lav_layernorm_fwd: ld must be a multiple of 8");
+    const bool x32 = f32io && f32io->x_f32;
+    float* y32 = f32io ? (float*)f32io->y32 : nullptr;
+    const long ldy32 = f32io ? f32io->ldy32 : 0;
+    LAV_REQUIRE(x && (y || y32) && gamma && beta, "lav_layernorm_fwd: null pointer");
+    LAV_REQUIRE(ldx % (x32 ? 4 : 8) == 0 && (!y || ldy % 8 == 0) && (!y32 || ldy32 % 4 == 0), "lav_layernorm_fwd: ld must keep rows 16-byte aligned");
     LnGeom geo;
     if (int rc = check_gather(gather, C, geo)) return rc;
     int G, iters;
     pick_geom(C, G, iters);
     hipStream_t s = (hipStream_t)stream;
-#define K_(G_, I_)                                                                                              \
-    hipLaunchKernelGGL((ln_fwd_kernel<G_, I_>), dim3((rows + 256 / G_ - 1) / (256 / G_)), dim3(256), 0, s, rows, C, \
-                       (const bf16_t*)x, ldx, geo, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd);
-    LN_DISPATCH(K_)
+#define K_(G_, I_, X_)                                                                                              \
+    hipLaunchKernelGGL((ln_fwd_kernel<G_, I_, X_>), dim3((rows + 256 / G_ - 1) / (256 / G_)), dim3(256), 0, s, rows, C, \
+                       x, ldx, geo, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd, y32, ldy32);
+    LN_DISPATCH(K_, x32)
 #undef K_
     return lav_check_launch("lav_layernorm_fwd");
 }
@@ -270,7 +295,7 @@ extern "C" int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, 
     LnBwdArgs a;
     memset(&a, 0, sizeof(a));
     if (int rc = check_gather(gather, C, a.geo)) return rc;
-    a.rows = rows; a.C = C; a.dy = (const bf16_t*)dy; a.lddy = lddy; a.x = (const bf16_t*)x; a.ldx = ldx;
+    a.rows = rows; a.C = C; a.dy = (const bf16_t*)dy; a.lddy = lddy; a.x = x; a.ldx = ldx;
     a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.add_in = (const bf16_t*)add_in; a.ldadd = ldadd;
     a.dx = (bf16_t*)dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta;
     if (extra) a.ex = *extra;
@@ -283,8 +308,9 @@ extern "C" int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, 
     if (grid > 768) grid = 768;         // 3 blocks per CU: enough loads in flight to stream, 2.7x fewer column atomics than 2048
     size_t lds = (size_t)rpw * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-#define K_(G_, I_) hipLaunchKernelGGL((ln_bwd_kernel<G_, I_>), dim3(grid), dim3(256), lds, s, a);
-    LN_DISPATCH(K_)
+#define K_(G_, I_, X_) hipLaunchKernelGGL((ln_bwd_kernel<G_, I_, X_>), dim3(grid), dim3(256), lds, s, a);
+    const bool x32 = a.ex.x_f32 != 0;
+    LN_DISPATCH(K_, x32)
 #undef K_
     return lav_check_launch("lav_layernorm_bwd");
 }

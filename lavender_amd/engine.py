@@ -47,6 +47,11 @@ _DW_SIDE = os.environ.get("LAV_DW_STREAM", "1") != "0"
 _GQ = 2 if os.environ.get("LAV_GELU_GRAD_U8", "0") != "0" else 1          # GELU' storage: 1 = bf16 (default), 2 = one byte per element (measured 0.8 ms/step SLOWER: the pack / unpack VALU work outweighs the bytes)
 _GQ_DT = torch.uint8 if _GQ == 2 else torch.bfloat16
 _dw_streams = {}
+# fp32 residual stream of the post-LN fusion encoder: the pre-LN sums x + dropout(dense(.)) and the LayerNorm outputs that
+# feed the next residual add stay fp32 (the GEMM operands are the bf16 copies).  Measured on the oracle with bf16 rounding
+# injected (tests/bf16_error_budget.py): this halves the logit error of the full-width model (mean 5.5e-3 -> 2.5e-3, max
+# 3.6e-2 -> 1.6e-2); the same change on the pre-LN Swin stream changes nothing, so the video side stays bf16.
+STREAM32 = os.environ.get("LAV_STREAM32", "1") != "0"
 
 
 def dw_stream(device):
@@ -378,8 +383,12 @@ class BertLayerFn(torch.autograd.Function):
     """One post-LN BertLayer of the fusion encoder (HF BertLayer as called from model.py:242)."""
 
     @staticmethod
-    def forward(ctx, anchor, x, layer, key_mask, n, L, p_hidden, p_attn):
+    def forward(ctx, anchor, x, x32, layer, key_mask, n, L, p_hidden, p_attn, want32):
+        """x: (R, H) bf16 layer input (GEMM operand); x32: its fp32 copy for the residual add, or None (first layer:
+        the embeddings are bf16); returns (y bf16, y32 fp32 or None when want32 is false)."""
         R, Hd = x.shape
+        f32 = torch.float32
+        sdt = f32 if STREAM32 else bf16
         heads = layer.num_heads
         arena = layer._arena()
         att_m = layer.attention.self
@@ -393,23 +402,28 @@ class BertLayerFn(torch.autograd.Function):
         cx = torch.empty((R, Hd), dtype=bf16, device=x.device)
         att.fwd(qkv, cx, lse)
         ao = layer.attention.output
-        pre1 = K.gemm(0, cx, W16(ao.dense.weight), R, Hd, Hd, bias=ao.dense.bias.data, dropout_p=p_hidden, seed=s1, residual=x)
+        pre1 = K.gemm(0, cx, W16(ao.dense.weight), R, Hd, Hd, bias=ao.dense.bias.data, dropout_p=p_hidden, seed=s1,
+                      residual=x32 if x32 is not None else x, out_dtype=sdt)
+        x1_32 = torch.empty((R, Hd), dtype=f32, device=x.device) if STREAM32 else None
         x1, mean1, rstd1 = K.layernorm_fwd(pre1, R, Hd, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, ao.LayerNorm.eps,
-                                           want_stats=keep)
+                                           want_stats=keep, out32=x1_32)
         inter, outp = layer.intermediate, layer.output
         F = inter.dense.weight.shape[0]
         h_pre = torch.empty((R, F), dtype=_GQ_DT, device=x.device) if keep else None
         h = K.gemm(0, x1, W16(inter.dense.weight), R, F, Hd, bias=inter.dense.bias.data, act=1, preact=h_pre, preact_is_grad=_GQ)
-        pre2 = K.gemm(0, h, W16(outp.dense.weight), R, Hd, F, bias=outp.dense.bias.data, dropout_p=p_hidden, seed=s2, residual=x1)
+        pre2 = K.gemm(0, h, W16(outp.dense.weight), R, Hd, F, bias=outp.dense.bias.data, dropout_p=p_hidden, seed=s2,
+                      residual=x1_32 if STREAM32 else x1, out_dtype=sdt)
+        y32 = torch.empty((R, Hd), dtype=f32, device=x.device) if (STREAM32 and want32) else None
         y, mean2, rstd2 = K.layernorm_fwd(pre2, R, Hd, outp.LayerNorm.weight.data, outp.LayerNorm.bias.data, outp.LayerNorm.eps,
-                                          want_stats=keep)
+                                          want_stats=keep, out32=y32)
         if keep:
             ctx.layer, ctx.att, ctx.seeds, ctx.p = layer, att, (s1, s2), p_hidden
             ctx.save_for_backward(x, qkv, cx, lse, pre1, mean1, rstd1, x1, h_pre, h, pre2, mean2, rstd2)
-        return y
+        ctx.mark_non_differentiable(*([y32] if y32 is not None else []))
+        return y, y32
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dy32=None):
         layer, att, (s1, s2), p = ctx.layer, ctx.att, ctx.seeds, ctx.p
         x, qkv, cx, lse, pre1, mean1, rstd1, x1, h_pre, h, pre2, mean2, rstd2 = ctx.saved_tensors
         R, Hd = x.shape
@@ -438,7 +452,7 @@ class BertLayerFn(torch.autograd.Function):
         att.bwd(qkv, cx, d_cx, lse, dqkv, None)
         dw_gemm(dqkv, x, 3 * Hd, Hd, R, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, R), rowsum_a=gbqkv)
         dx = K.gemm(0, dqkv, W16T(att_m.query.weight), R, Hd, 3 * Hd, residual=d_pre1)
-        return None, dx, None, None, None, None, None, None
+        return None, dx, None, None, None, None, None, None, None, None
 
 
 class MLMHeadFn(torch.autograd.Function):

@@ -56,6 +56,7 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
     e.rows_per_group = int(rows_per_group)
     e.residual = _p(residual)
     e.ldr = _ld(residual) if residual is not None else 0
+    e.residual_f32 = int(residual is not None and residual.dtype == torch.float32)
     e.colsum = _p(colsum)
     e.alpha = float(alpha)
     e.out_mode = 2 if accumulate else (1 if out.dtype == torch.float32 else 0)
@@ -111,14 +112,22 @@ def _gather(g):
     return C.byref(s)
 
 
-def layernorm_fwd(x, rows, Cn, gamma, beta, eps, gather=None, out=None, want_stats=True):
+def layernorm_fwd(x, rows, Cn, gamma, beta, eps, gather=None, out=None, want_stats=True, out32=None, want16=True):
+    """x bf16 or fp32 (the fp32 residual stream); out32: optional fp32 copy of the output (then returned 4th)."""
     dev = x.device
-    y = out if out is not None else torch.empty((rows, Cn), dtype=bf16, device=dev)
+    y = out if out is not None else (torch.empty((rows, Cn), dtype=bf16, device=dev) if want16 else None)
     mean = torch.empty(rows, dtype=torch.float32, device=dev) if want_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=dev) if want_stats else None
     ldx = gather[2] if gather is not None else _ld(x)
+    f = None
+    if x.dtype == torch.float32 or out32 is not None:
+        st = L.LnF32()
+        st.x_f32 = int(x.dtype == torch.float32)
+        st.y32 = _p(out32)
+        st.ldy32 = _ld(out32) if out32 is not None else 0
+        f = C.byref(st)
     L.check(L.lib.lav_layernorm_fwd(_s(), rows, Cn, _p(x), ldx, _gather(gather), _p(gamma), _p(beta), float(eps), _p(y),
-                                    _ld(y), _p(mean), _p(rstd)), "lav_layernorm_fwd")
+                                    _ld(y) if y is not None else 0, _p(mean), _p(rstd), f), "lav_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -130,8 +139,10 @@ def layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dgamma, dbeta, gather=None
     ldx = gather[2] if gather is not None else _ld(x)
     lddx = gather[2] if gather is not None else _ld(dx)
     ex = None
-    if dx2 is not None or colsum is not None:
+    x32 = x.dtype == torch.float32
+    if dx2 is not None or colsum is not None or x32:
         s = L.LnBwdExtra()
+        s.x_f32 = int(x32)
         s.dx2 = _p(dx2)
         s.lddx2 = _ld(dx2) if dx2 is not None else 0
         s.row_scale = _p(row_scale)
@@ -201,7 +212,7 @@ def window_tables(device, D, H, W, window, shift):
 class Attn:
     """Descriptor + scratch for one attention call (window or sequence mode)."""
 
-    def __init__(self, mode, heads, head_dim, **kw):
+    def __init__(self, mode, heads, head_dim, fast=True, **kw):
         d = L.AttnDesc()
         d.mode, d.heads, d.head_dim = mode, heads, head_dim
         d.scale = float(head_dim) ** -0.5
@@ -212,7 +223,7 @@ class Attn:
                 setattr(d, k, v)
         self.d = d
         self._keep = kw
-        if mode == 0 and kw["wd"] * kw["wh"] * kw["ww"] <= 256:
+        if mode == 0 and fast and kw["wd"] * kw["wh"] * kw["ww"] <= 256:
             # fast path: precomputed token rows + fragment-ordered (bias + mask) tables, rebuilt from the
             # current bias table (one small kernel per call site per step)
             dev = kw["bias_table"].device
@@ -346,3 +357,35 @@ def cast_bf16(src, dst, n):
 
 def fill_droppath(n_blocks, B, keep_prob, seed, out):
     L.check(L.lib.lav_fill_droppath(_s(), n_blocks, B, _p(keep_prob), int(seed) & 0xFFFFFFFF, _p(out)), "lav_fill_droppath")
+
+
+# ---- fp32-I/O validation mode (csrc/validate.hip; see lavender_amd/validate.py) ---------------------------------------
+def v_gemm(A, B, out, M, N, K, bias=None, act=0, residual=None):
+    """out[M,N] = act(A[M,K] . B[N,K]^T + bias) + residual, everything fp32."""
+    for t in (A, B, out, bias, residual):
+        assert t is None or t.dtype == torch.float32
+    L.check(L.lib.lav_v_gemm_f32(_s(), M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out), _p(bias), int(act), _p(residual),
+                                 _ld(residual) if residual is not None else 0), "lav_v_gemm_f32")
+    return out
+
+
+def v_attention(att, qkv, out, pad_qkv=None):
+    L.check(L.lib.lav_v_attention_f32(_s(), C.byref(att.d), _p(qkv), _p(out), _p(pad_qkv)), "lav_v_attention_f32")
+
+
+def v_im2col(img, B, T, H, W, frame_major, out):
+    L.check(L.lib.lav_v_im2col_f32(_s(), _p(img), B, T, H, W, int(frame_major), _p(out)), "lav_v_im2col_f32")
+
+
+def v_video_embed(feat, B, T, hw, Hd, cls, pos, len_, gamma, beta, eps, out, seq_rows):
+    L.check(L.lib.lav_v_video_embed_f32(_s(), B, T, hw, Hd, _p(feat), _p(cls), _p(pos), _p(len_), _p(gamma), _p(beta), float(eps),
+                                        _p(out), int(seq_rows)), "lav_v_video_embed_f32")
+
+
+def v_text_embed(ids, n, X, Hd, word, pos, type0, gamma, beta, eps, out):
+    L.check(L.lib.lav_v_text_embed_f32(_s(), n, X, Hd, _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), float(eps),
+                                       _p(out)), "lav_v_text_embed_f32")
+
+
+def v_gather_rows(src, src_row, n_rows, Cn, out):
+    L.check(L.lib.lav_v_gather_rows_f32(_s(), n_rows, Cn, _p(src), _ld(src), _p(src_row), _p(out), _ld(out)), "lav_v_gather_rows_f32")

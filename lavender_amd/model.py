@@ -168,8 +168,9 @@ class LAVENDER_Base(nn.Module):
             x = x.contiguous()
         ph = self.config.hidden_dropout_prob if self.training else 0.0
         pa = self.config.attention_probs_dropout_prob if self.training else 0.0
-        for lyr in self.trsfr.layer:
-            x = E.BertLayerFn.apply(arena.anchor, x, lyr, km, n, L, ph, pa)
+        x32, last = None, len(self.trsfr.layer) - 1
+        for i, lyr in enumerate(self.trsfr.layer):
+            x, x32 = E.BertLayerFn.apply(arena.anchor, x, x32, lyr, km, n, L, ph, pa, i < last)
         return x.view(n, L, Hd)
 
     def go_cross(self, feat_img, mask_img, feat_txt, mask_txt, attn_mask_type="full", feat_pretxt=None, mask_pretxt=None):

@@ -16,6 +16,11 @@ import os as _os
 _MERGE_PASSES = _os.environ.get("LAV_MERGE_PASSES", "1") != "0"
 
 
+def fp32_validation(args):
+    """args.validate_fp32 = True or LAV_FP32=1 selects the fp32-I/O validation forward (lavender_amd/validate.py)."""
+    return bool(getattr(args, "validate_fp32", False)) or _os.environ.get("LAV_FP32", "0") == "1"
+
+
 def vtm_pairs(B, O):
     """Pair list of main_pretrain_mlm.py:74-106: per sample i -> (i,i,true) then O-1 negatives drawn with ONE
     np.random.permutation([j != i]) -- same RNG call sequence, hence the same negatives, as the reference."""
@@ -60,6 +65,14 @@ class LAVENDER_Pretrain_MLM(LAVENDER_Base):
     def forward(self, batch):
         """main_pretrain_mlm.py:55-119.  Same outputs; the B*O python loop of slices + T.cat is replaced by an
         index list (same numpy RNG draws) consumed by one gather kernel."""
+        if fp32_validation(self.args):
+            # tier-T2 validation mode (north_star "MLM logits within 1e-3 of reference"): fp32 activations end to end,
+            # forward only, eval arithmetic -- lavender_amd/validate.py
+            if self.training:
+                raise RuntimeError("the fp32 validation mode is forward-only (eval arithmetic): call model.eval() first")
+            from . import validate
+            with torch.no_grad():
+                return validate.pretrain_mlm_forward(self, batch)
         batch = defaultdict(lambda: None, batch)
         img, txt, mask = [batch[key] for key in ["img", "txt", "mask"]]
         vt_mask, ans_mtm = batch["vt_mask"], batch["ans_mtm"]

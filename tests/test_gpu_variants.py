@@ -82,10 +82,24 @@ def test_task_specific_pretrain_matches_oracle_and_golden(golden_dir):
     torch.cuda.synchronize()
     print("loss", ls_mtm.item(), ls_vtm.item(), "golden", g["loss"])
     assert abs(ls_mtm.item() - g["loss"][0]) < 1e-2 and abs(ls_vtm.item() - g["loss"][1]) < 1e-2
-    # In this fixture the O texts paired with one video give almost identical hidden states (scores differ by ~2e-3,
-    # loss = ln 4), so d/d(fc.*) = sum_o (p_o - 1[o=0]) h_o is a difference of nearly equal bf16 rows: noise-dominated.
-    # The arithmetic of the score head is checked in isolation by test_score_head_stage_against_fp32_torch.
-    _grad_check(m, P, skip=("fc.1.weight", "fc.1.bias", "fc.3.weight", "fc.3.bias"), rel_tol=0.10)
+    # Gradients: at the shipped temperature 0.05 the matching scores are the bf16 hidden-state error times 20, and in this
+    # fixture the O texts of one video give almost identical hidden states (scores differ by ~2e-3, loss = ln 4), so
+    # d(loss)/d(anything) through the score head is noise-dominated.  The gradient comparison therefore runs the SAME model
+    # and inputs at temp = 1 (a well-conditioned problem), oracle and HIP alike; the arithmetic of the score head itself
+    # is checked in isolation by test_score_head_stage_against_fp32_torch.
+    for v in P.values():
+        v.grad = None
+    np.random.seed(88)
+    ref = R.pretrain_ts_forward(P, batch, swin, heads, 1.0)
+    l1, l2 = R.pretrain_ts_loss(ref)
+    (l1 + l2).backward()
+    m.args.temp = 1.0
+    m.arena().zero_grad()
+    np.random.seed(88)
+    out = m(batch["img"].cuda(), batch["txt"].cuda(), batch["mask"].cuda(), ans.cuda())
+    (lf(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten()) + lf(out["out_vtm"], out["ans_vtm"], count=B)).backward()
+    torch.cuda.synchronize()
+    _grad_check(m, P, skip=("fc.1.weight", "fc.1.bias", "fc.3.weight", "fc.3.bias"), rel_tol=0.08)
 
 
 def test_score_head_stage_against_fp32_torch():
