@@ -263,10 +263,13 @@ def extended_mask(mask, dtype=torch.float32):
     return (1.0 - mask[:, None, None, :].to(dtype)) * torch.finfo(dtype).min
 
 
-def bert_layer(P, pre, x, add_mask, heads):
-    """One post-LN BERT layer (the fusion encoder, model.py:242)."""
+def bert_layer(P, pre, x, add_mask, heads, drop=None):
+    """One post-LN BERT layer (the fusion encoder, model.py:242).  drop: None (eval) or the sampled dropout masks of a
+    training step as multipliers (0 or 1/(1-p)): (attention probabilities (B,heads,L,L), attention-output hidden (B,L,H),
+    FFN-output hidden (B,L,H)) -- HF BertSelfAttention / BertSelfOutput / BertOutput dropout placement."""
     B, L, Hd = x.shape
     hd = Hd // heads
+    d_att, d_h1, d_h2 = drop if drop is not None else (None, None, None)
 
     def split(t):
         return t.reshape(B, L, heads, hd).transpose(1, 2)
@@ -274,9 +277,17 @@ def bert_layer(P, pre, x, add_mask, heads):
     k = split(_lin(x, P, pre + ".attention.self.key"))
     v = split(_lin(x, P, pre + ".attention.self.value"))
     s = q @ k.transpose(-1, -2) * hd ** -0.5 + add_mask
-    ctx = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, L, Hd)
-    x = _ln(_lin(ctx, P, pre + ".attention.output.dense") + x, P, pre + ".attention.output.LayerNorm", 1e-12)
+    pr = s.softmax(-1)
+    if d_att is not None:
+        pr = pr * d_att
+    ctx = (pr @ v).transpose(1, 2).reshape(B, L, Hd)
+    a = _lin(ctx, P, pre + ".attention.output.dense")
+    if d_h1 is not None:
+        a = a * d_h1
+    x = _ln(a + x, P, pre + ".attention.output.LayerNorm", 1e-12)
     h = _lin(F.gelu(_lin(x, P, pre + ".intermediate.dense")), P, pre + ".output.dense")
+    if d_h2 is not None:
+        h = h * d_h2
     return _ln(h + x, P, pre + ".output.LayerNorm", 1e-12)
 
 
@@ -287,12 +298,12 @@ def n_fusion_layers(P):
     return n
 
 
-def go_cross(P, f_img, m_img, f_txt, m_txt, heads):
-    """LAVENDER_Base.go_cross, model.py:223-243 ("full" mask)."""
+def go_cross(P, f_img, m_img, f_txt, m_txt, heads, drops=None):
+    """LAVENDER_Base.go_cross, model.py:223-243 ("full" mask).  drops: per-layer dropout multipliers (see bert_layer)."""
     x = torch.cat([f_img, f_txt], 1)
     add = extended_mask(torch.cat([m_img, m_txt], 1))
     for i in range(n_fusion_layers(P)):
-        x = bert_layer(P, f"trsfr.layer.{i}", x, add, heads)
+        x = bert_layer(P, f"trsfr.layer.{i}", x, add, heads, None if drops is None else drops[i])
     return x
 
 
@@ -338,19 +349,20 @@ def vtm_pairs(B, O):
     return np.array(vi), np.array(ti), np.array(tr)
 
 
-def pretrain_forward(P, batch, size, heads, droppath=None, vtm_batch=4, ids=SPECIAL, taps=None):
-    """LAVENDER_Pretrain_MLM.forward, main_pretrain_mlm.py:55-119 (eval-mode arithmetic:
-    no dropout; optional explicit drop-path factors)."""
+def pretrain_forward(P, batch, size, heads, droppath=None, vtm_batch=4, ids=SPECIAL, taps=None, drop=None):
+    """LAVENDER_Pretrain_MLM.forward, main_pretrain_mlm.py:55-119.  Default: eval-mode arithmetic.  A training step is
+    reproduced by passing the masks it sampled: droppath = per-block (scale_attn, scale_mlp) stochastic-depth factors and
+    drop = dict(txt=(B,X,H) multiplier of the text-embedding dropout, mtm=[per layer], vtm=[per layer]) (see bert_layer)."""
     img, txt, mask = batch["img"], batch["txt"], batch["mask"]
     B, X = txt.shape
     O = min(B, vtm_batch)
     f_img, m_img = enc_video(P, img, size, droppath, taps)
-    f_txt = enc_txt(P, txt)
+    f_txt = enc_txt(P, txt, None if drop is None else drop["txt"])
     Lv = f_img.shape[1]
-    out = go_cross(P, f_img, m_img, f_txt, mask, heads)
+    out = go_cross(P, f_img, m_img, f_txt, mask, heads, None if drop is None else drop["mtm"])
     out_mtm = mlm_head(P, out[:, Lv:])
     vi, ti, tr = vtm_pairs(B, O)
-    out = go_cross(P, f_img[vi], m_img[vi], f_txt[ti], mask[ti], heads)
+    out = go_cross(P, f_img[vi], m_img[vi], f_txt[ti], mask[ti], heads, None if drop is None else drop["vtm"])
     out_vtm = mlm_head(P, out[:, Lv:])
     ans_vtm = torch.full((B * O, X), -1, dtype=torch.long)
     ans_vtm[:, -1] = torch.where(torch.from_numpy(tr), ids["true"], ids["false"])

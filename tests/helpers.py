@@ -78,3 +78,39 @@ def build_filled_model(swin, bert, B, device="cuda", cls=None):
     m.to(device)
     m.arena()
     return m
+
+
+# ---- the counter-hash dropout of the HIP kernels, restated on the host (lavender_amd/csrc/common.h: lav_keep / lav_hash32) ----
+# keep(seed, idx) is a pure function, so a training step's masks can be rebuilt exactly from the seeds it drew and handed to
+# the oracle (oracle.pretrain_forward(drop=..., droppath=...)): train-mode gradients are then comparable tensor by tensor.
+def _hash32(seed, idx):
+    h = (idx.astype(np.uint64) * np.uint64(0x9E3779B1) + np.uint64(seed)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    return h
+
+
+def hidden_keep_multiplier(seed, rows, cols, p):
+    """GEMM-epilogue / text-embedding dropout: element (row, col) has index row * cols + col; keep iff hash >= p * 2^32."""
+    idx = (np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(cols) + np.arange(cols, dtype=np.uint64)[None, :]) & np.uint64(0xFFFFFFFF)
+    thresh = min(int(float(np.float32(p)) * 4294967296.0), 4294967295)
+    keep = _hash32(seed, idx) >= np.uint64(thresh)
+    return torch.from_numpy(keep.astype(np.float32) / (1.0 - float(np.float32(p))))
+
+
+def attn_keep_multiplier(seed, n, heads, L, p):
+    """Attention-probability dropout of the sequence kernels: one hash per (sequence*heads+head, query, key pair); the even
+    key takes the low 16 bits, the odd key the high 16 bits; keep iff that half >= round(p * 65536)."""
+    NH = (L + 1) // 2
+    t16 = min(int(float(np.float32(p)) * 65536.0 + 0.5), 65535)
+    ph = np.arange(n * heads, dtype=np.uint64)[:, None, None]
+    q = np.arange(L, dtype=np.uint64)[None, :, None]
+    kp = np.arange(NH, dtype=np.uint64)[None, None, :]
+    idx = ((ph * np.uint64(L) + q) * np.uint64(NH) + kp) & np.uint64(0xFFFFFFFF)
+    h = _hash32(seed, idx)
+    keep = np.empty((n * heads, L, 2 * NH), dtype=bool)
+    keep[:, :, 0::2] = (h & np.uint64(0xFFFF)) >= np.uint64(t16)
+    keep[:, :, 1::2] = (h >> np.uint64(16)) >= np.uint64(t16)
+    keep = keep[:, :, :L].reshape(n, heads, L, L)
+    return torch.from_numpy(keep.astype(np.float32) / (1.0 - float(np.float32(p))))

@@ -67,11 +67,13 @@ def test_forward_matches_oracle_and_golden(golden_dir, case):
         d = (a - b).abs()
         agree = (a.argmax(-1) == b.argmax(-1)).float().mean().item()
         print(key, "max", d.max().item(), "mean", d.mean().item(), "argmax agree", agree)
-        assert d.max() < 3e-2 and d.mean() < 5e-3 and agree >= 0.9
-        # wherever the argmax differs, the oracle's own top-1 margin over our choice is inside the logit tolerance
-        # (near-ties of the key-filled weights), i.e. no disagreement is a real one
+        # micro widths (vocab 8192, logits of rms 0.05): measured max 5.6e-3 / mean 8e-4.  The key-filled micro weights give
+        # 1-2 exact near-ties among the 64-160 positions, so the argmax floor here is 0.95 and every disagreement must be a
+        # near-tie of the ORACLE itself (its top-1 margin over our choice below the logit tolerance); the 0.97 floor of tier T3
+        # is asserted at the Tiny and Base widths below
+        assert d.max() < 1.5e-2 and d.mean() < 2.5e-3 and agree >= 0.95
         margin = b.max(-1).values - b.gather(-1, a.argmax(-1, keepdim=True)).squeeze(-1)
-        assert margin.max() < 3e-2, margin.max().item()
+        assert margin.max() < 1e-2, margin.max().item()
         cols = torch.from_numpy(g["cols"])
         np.testing.assert_allclose(a[:, :, cols].numpy(), g[key + "_cols"], atol=3e-2)
 
@@ -102,7 +104,7 @@ def test_loss_and_gradients_match_oracle(golden_dir, case):
     print("loss", ls_mtm.item(), ls_vtm.item(), "ref", l1.item(), l2.item(), "golden", g["loss"])
     assert abs(ls_mtm.item() - l1.item()) < 1e-2 and abs(ls_vtm.item() - l2.item()) < 1e-2
     assert abs(ls_mtm.item() - g["loss"][0]) < 1e-2 and abs(ls_vtm.item() - g["loss"][1]) < 1e-2
-    bad = []
+    bad, worst = [], 0.0
     for name, p in m.named_parameters():
         gref = P[name].grad
         if gref is None:
@@ -114,8 +116,10 @@ def test_loss_and_gradients_match_oracle(golden_dir, case):
             continue
         rel = (a - b).norm() / (b.norm() + 1e-12)
         cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
-        if not (rel < 0.08 and cos > 0.995):
+        worst = max(worst, rel.item())
+        if not (rel < 0.05 and cos > 0.998):
             bad.append((name, rel.item(), cos, b.norm().item()))
+    print('worst relative gradient error', worst)
     assert not bad, bad[:20]
 
 
@@ -211,7 +215,7 @@ def test_base_12l_forward_and_loss_vs_oracle():
         margin = (b.max(-1).values - b.gather(-1, a.argmax(-1, keepdim=True)).squeeze(-1)).max().item()
         print(key, "max", d.max().item(), "mean", d.mean().item(), "argmax agree", agree, "margin at disagreements", margin,
               "logit rms", b.pow(2).mean().sqrt().item())
-        # measured: max 3.8e-2 / 4.4e-2, mean 5.7e-3 on logits of rms 0.56 (1 % relative after 36 blocks of bf16 storage)
-        assert d.max() < 8e-2 and d.mean() < 8e-3 and margin < 6e-2
+        # tier T3 at the headline width (the fusion encoder keeps its residual stream in fp32)
+        assert d.max() < 3e-2 and d.mean() < 5e-3 and agree >= 0.97 and margin < 3e-2
     print("loss", ls_mtm.item(), ls_vtm.item(), "oracle", l1.item(), l2.item())
     assert abs(ls_mtm.item() - l1.item()) < 1e-2 and abs(ls_vtm.item() - l2.item()) < 1e-2
