@@ -107,8 +107,11 @@ def cpu_baseline(timeout_s=240):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="launch check only (no model, works without a GPU over gloo): every rank joins the process group, "
+                         "all-reduces a one and rank 0 prints the observed world size")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 32 (cfg2), 8 (cfg4, cfg5)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                     help="BASELINE.json configs: cfg2 = headline (Swin-B 224, pretrain MLM); cfg4 = Swin-L 384^2 pretrain; "
@@ -124,16 +127,43 @@ def main():
         cpu_baseline_child()
         return
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: spawn the N ranks ourselves (same launcher the driver uses) instead
+        # of silently running one rank and labelling it N GPUs
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == a.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {a.gpus}"
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {a.gpus}: refusing to report a {world}-rank run as {a.gpus} GPUs")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend="nccl" if use_cuda else "gloo", init_method="env://")
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus says {a.gpus}")
+    if a.selftest_launch:
+        seen = 1
+        if world > 1:
+            t = torch.ones(1, device="cuda" if use_cuda else "cpu")
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"selftest_launch": True, "n_gpus": a.gpus, "world_observed": seen,
+                              "backend": ("nccl" if use_cuda else "gloo") if world > 1 else None}))
+        return
 
     import lavender_amd as LA
     from lavender_amd import hip as K
@@ -193,11 +223,16 @@ def main():
     for i in range(a.warmup):
         run_step(i)
     barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
+    evs[0].record()
     for i in range(a.steps):
         last = run_step(i)
+        evs[i + 1].record()                              # per-step marks on the main stream (median below); the contract value uses the wall clock
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
+    ms_median = step_ms[len(step_ms) // 2]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -283,7 +318,8 @@ def main():
         if a.loss_aware_head:
             what = "SIDE CASE loss-aware head (labelled positions only, not the reference's full-logit outputs) -- " + what
         out = {"metric": "video-text samples/sec (node) pretrain step, Swin-B 5x224^2 + 32-tok", "value": round(value, 2),
-               "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
+               "unit": "samples/s", "n_gpus": world, "world_size_observed": (dist.get_world_size() if world > 1 else 1),
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "ms_per_step_median_hip_events": round(ms_median, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"{what}Swin-{a.size}-K600-22k + {a.layers}-layer fusion + MLM head, "
                                       f"{'main_retrieval_mlm' if retrieval else 'main_pretrain_mlm'} path, "

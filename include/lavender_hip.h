@@ -223,6 +223,10 @@ int lav_gather_sum_rows(void* stream, int n_out, int C, const void* src, long ld
 int lav_cross_entropy_fwd_bwd(void* stream, int rows, int V, void* logits, long ld, const int64_t* labels,
                               float* loss_sum, float grad_scale, int write_grad /* 0: loss only, logits untouched */);
 int lav_scale_by_count(void* stream, long n_elems, void* x_bf16, const float* loss_sum, float gscale);
+/* x (bf16, or fp32 when x_is_f32) *= scalar_dev[0], the scalar read on the device: applies the upstream autograd gradient
+ * of a loss (gradient accumulation loss / k, loss weights, a GradScaler) to the stored d(loss)/d(logits) without a host
+ * sync; a scalar of exactly 1 returns after one load.  n_elems % 8 == 0. */
+int lav_scale_by_scalar(void* stream, long n_elems, void* x, int x_is_f32, const float* scalar_dev);
 /* same contract on FP32 logits with few classes (the (B, O) matching scores of the task-specific variant) */
 int lav_cross_entropy_f32_fwd_bwd(void* stream, int rows, int V, float* logits, long ld, const int64_t* labels,
                                   float* loss_sum, float grad_scale, int write_grad);
@@ -251,7 +255,9 @@ int lav_pair_score_bwd(void* stream, int n, int F, const void* dlogits, long ld,
  *   writes the bf16 working copy used by the GEMMs. */
 int lav_sumsq_f32(void* stream, long n, const float* g, float* out);
 int lav_adamw_step(void* stream, long n, float* p, const float* g, float* m, float* v, void* p_bf16,
-                   const uint8_t* block_group /* group id (0..3) per 64-element block of the arena */,
+                   const uint8_t* block_group /* per 64-element block of the arena: bits 0-1 group id (0..3), bit 2 = the
+                                                 block belongs to a parameter that never gets a gradient on this path
+                                                 (grad None in the reference: AdamW skips it, no decay) */,
                    const float lr[4], const float wd[4], float beta1, float beta2, float eps, int step,
                    const float* gradsq, float max_norm, float grad_div);
 /* Transposed bf16 working copy of the weight matrices: every nn.Linear backward-to-input (dx = dy W, the autograd of

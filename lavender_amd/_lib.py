@@ -76,6 +76,7 @@ _SIGS = {
     "lav_gather_sum_rows": (i32, [vp, i32, i32, vp, i64, vp, vp, vp, i64]),
     "lav_cross_entropy_fwd_bwd": (i32, [vp, i32, i32, vp, i64, vp, vp, f32, i32]),
     "lav_scale_by_count": (i32, [vp, i64, vp, vp, f32]),
+    "lav_scale_by_scalar": (i32, [vp, i64, vp, i32, vp]),
     "lav_cross_entropy_f32_fwd_bwd": (i32, [vp, i32, i32, vp, i64, vp, vp, f32, i32]),
     "lav_transpose_bf16_batched": (i32, [vp, i32, vp, i32, vp, vp]),
     "lav_pair_score_fwd": (i32, [vp, i32, i32, vp, i64, vp, vp, f32, i32, vp, i64]),

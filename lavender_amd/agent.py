@@ -62,11 +62,14 @@ class ArenaAdamW:
         self.betas, self.eps = betas, eps
         self.steps = 0
 
-    def step(self, max_norm=-1.0, grad_div=1.0):
+    def step(self, max_norm=-1.0, grad_div=1.0, dp=None):
         self.steps += 1
         a = self.model.arena()
-        a.adamw_step([g["lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups], self.steps,
-                     max_norm, grad_div, self.betas, self.eps)
+        lr4, wd4 = [g["lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups]
+        if dp is not None:
+            dp.optimizer_step(a, lr4, wd4, self.steps, max_norm, self.betas, self.eps)      # DDP: plain step; ZeRO-1: sharded step + all-gather
+        else:
+            a.adamw_step(lr4, wd4, self.steps, max_norm, grad_div, self.betas, self.eps)
 
     def zero_grad(self, set_to_none=False):
         self.model.arena().zero_grad()
@@ -132,6 +135,8 @@ class Agent_Base:
 
     def save_model(self, ep):
         """agent.py:164-180: rank-0 torch.save of the CPU state_dict under the reference's file name."""
+        if self.dp is not None:
+            self.dp.gather_master()                         # ZeRO-1: every rank takes part in re-assembling the fp32 masters
         if is_main_process():
             output_dir = self.args.path_output
             os.makedirs(output_dir, exist_ok=True)
@@ -162,21 +167,25 @@ class Agent_Base:
         raise TypeError(f"batch is either dict or tuple, {type(batch)}")
 
     def backward_step(self, loss):
-        """agent.py:235-250: backward, (all-reduce,) clip by global norm, AdamW, LR schedule, zero_grad."""
+        """agent.py:235-250: backward, (gradient exchange,) clip by global norm, AdamW, LR schedule, zero_grad."""
+        if self.dp is not None:
+            self.dp.begin_step()
         loss.backward()
         from .engine import dw_join
         dw_join()                                          # weight-gradient kernels run on a side stream
-        world = 1
         if self.dp is not None:
             self.dp.finish()
-            world = self.dp.world
-        self.optzr.step(max_norm=self.args.max_grad_norm, grad_div=float(world))
+        self.optzr.step(max_norm=self.args.max_grad_norm, dp=self.dp)
         self.lr_scheduler.step()
         self.optzr.zero_grad()
         self.global_step += 1
 
     def prepare_dist_model(self):
-        """agent.py:252-265: instead of wrapping in DDP / DeepSpeed, attach the arena gradient reducer."""
+        """agent.py:252-265: instead of wrapping in DDP (default) or DeepSpeed ZeRO-1 (args.deepspeed), attach the matching
+        arena gradient reducer (lavender_amd.dp)."""
         if get_world_size() > 1:
-            from .dp import ArenaReducer
-            self.dp = ArenaReducer(self._unwrapped())
+            from .dp import ArenaReducer, ZeroOneReducer
+            if getattr(self.args, "deepspeed", False):
+                self.dp = ZeroOneReducer(self._unwrapped())
+            else:
+                self.dp = ArenaReducer(self._unwrapped())

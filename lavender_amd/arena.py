@@ -19,6 +19,9 @@ from . import hip as K
 
 ALIGN = 64
 SLACK = 64 * 1024
+# parameters that never receive a gradient on the paths built here (after one pretrain step exactly these
+# have grad None in the reference, so torch.optim.AdamW never touches them -- no weight decay either); bit 2 of block_group
+NO_GRAD_PARAMS = ("emb_task", "enc_img.emb_odr")
 _QKV = re.compile(r"(.*attention\.self)\.(query|key|value)\.(weight|bias)$")
 
 
@@ -67,7 +70,10 @@ class ParamArena:
         self.master = torch.zeros(off + SLACK, dtype=torch.float32, device=self.device)[:off]
         self.half_full = torch.zeros(off + SLACK, dtype=torch.bfloat16, device=self.device)
         self.half = self.half_full[:off]
-        self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        # same slack behind the gradients: the ZeRO-1 reduce-scatter works on world x shard elements (shard = the arena
+        # split into 64-aligned equal parts), which may reach a few blocks past the last parameter
+        self.grad_full = torch.zeros(off + SLACK, dtype=torch.float32, device=self.device)
+        self.grad = self.grad_full[:off]
         grp = torch.zeros(off // ALIGN, dtype=torch.uint8)
         self.params = {}
         for n, p in named:
@@ -78,7 +84,7 @@ class ParamArena:
             p._lav16 = self.half[o:o + k].view(p.shape)
             p._lavg = p.grad
             p._lav_name = n
-            grp[o // ALIGN:(o + k + ALIGN - 1) // ALIGN] = param_group_of(n)
+            grp[o // ALIGN:(o + k + ALIGN - 1) // ALIGN] = param_group_of(n) | (4 if n in NO_GRAD_PARAMS else 0)
             self.params[n] = p
         self.block_group = grp.to(self.device)
         self._build_transposed(named)
@@ -166,20 +172,32 @@ class ParamArena:
     def zero_grad(self):
         from .engine import dw_join
         dw_join()
-        self.grad.zero_()
+        self.grad_full.zero_()
         for p in self.params.values():
             if p.grad is None or p.grad.data_ptr() != p._lavg.data_ptr():
                 p.grad = p._lavg
 
-    def adamw_step(self, lr4, wd4, step, max_norm, grad_div=1.0, betas=(0.9, 0.98), eps=1e-8):
+    def adamw_step(self, lr4, wd4, step, max_norm, grad_div=1.0, betas=(0.9, 0.98), eps=1e-8, shard=None, sum_gradsq=None):
+        """One fused clip + AdamW + bf16-refresh launch.  shard = (lo, hi): ZeRO-1 -- this rank owns (and keeps the
+        optimizer state of) arena elements [lo, hi) only; `sum_gradsq(t)` then sums the 1-element squared-norm tensor over
+        the ranks (each contributes its own shard of the already reduced gradient)."""
         from .engine import dw_join
         dw_join()                                             # weight-gradient kernels run on a side stream
-        if self.m is None:
-            self.m = torch.zeros_like(self.master)
-            self.v = torch.zeros_like(self.master)
+        lo, hi = (0, self.total) if shard is None else shard
+        n = hi - lo
+        if self.m is None or self.m.numel() != n:
+            self.m = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.v = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.gradsq.zero_()
+        if n <= 0:
+            if max_norm > 0 and sum_gradsq is not None:
+                sum_gradsq(self.gradsq)
+            return
         if max_norm > 0:
-            K.sumsq(self.grad, self.total, self.gradsq)
-        K.adamw(self.total, self.master, self.grad, self.m, self.v, self.half, self.block_group, lr4, wd4, betas[0], betas[1],
-                eps, step, self.gradsq if max_norm > 0 else None, max_norm, grad_div)
-        self.sync_transposed()
+            K.sumsq(self.grad[lo:hi], n, self.gradsq)
+            if sum_gradsq is not None:
+                sum_gradsq(self.gradsq)
+        K.adamw(n, self.master[lo:hi], self.grad[lo:hi], self.m, self.v, self.half[lo:hi], self.block_group[lo // ALIGN:hi // ALIGN],
+                lr4, wd4, betas[0], betas[1], eps, step, self.gradsq if max_norm > 0 else None, max_norm, grad_div)
+        if shard is None:
+            self.sync_transposed()

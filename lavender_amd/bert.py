@@ -160,8 +160,11 @@ class BertOnlyMLMHead(nn.Module):
 
 
 def load_hf_state(path, prefix_map):
-    """Best-effort read of a HF checkpoint directory (model.safetensors / pytorch_model.bin) -> {our key: tensor}.
-    prefix_map: list of (hf_prefix, our_prefix).  Returns {} when `path` is not a local directory with weights."""
+    """Read a HF checkpoint directory (model.safetensors / pytorch_model.bin) -> {our key: tensor}.
+    prefix_map: list of (hf_prefix, our_prefix).  Returns {} when `path` is not a local directory with weights.
+    Mirrors what `from_pretrained` does for the keys the reference keeps (model.py:100-102,152-165, main_pretrain_mlm.py:46-48):
+    legacy TF-style LayerNorm names (`LayerNorm.gamma` / `LayerNorm.beta`, as in the stock bert-base-uncased file) become
+    `.weight` / `.bias`, and a checkpoint without `cls.predictions.decoder.weight` gets it from the tied word embeddings."""
     if not isinstance(path, str) or not os.path.isdir(path):
         return {}
     sd = None
@@ -174,6 +177,14 @@ def load_hf_state(path, prefix_map):
         sd = torch.load(pt, map_location="cpu")
     if sd is None:
         return {}
+    sd = {k.replace("LayerNorm.gamma", "LayerNorm.weight").replace("LayerNorm.beta", "LayerNorm.bias"): v for k, v in sd.items()}
+    if "cls.predictions.decoder.weight" not in sd:
+        for emb in ("bert.embeddings.word_embeddings.weight", "embeddings.word_embeddings.weight"):
+            if emb in sd and any(k.startswith("cls.predictions.") for k in sd):
+                sd["cls.predictions.decoder.weight"] = sd[emb]
+                break
+    if "cls.predictions.decoder.bias" not in sd and "cls.predictions.bias" in sd:
+        sd["cls.predictions.decoder.bias"] = sd["cls.predictions.bias"]
     out = {}
     for k, v in sd.items():
         for hp, op in prefix_map:
@@ -181,3 +192,12 @@ def load_hf_state(path, prefix_map):
                 out[op + k[len(hp):]] = v
                 break
     return out
+
+
+def load_hf_into(module, sd, what, ignore=("position_ids", "token_type_ids")):
+    """module.load_state_dict(sd, strict=False) that REPORTS what did not match instead of dropping it silently."""
+    sd = {k: v for k, v in sd.items() if not any(s in k for s in ignore)}
+    res = module.load_state_dict(sd, strict=False)
+    if res.missing_keys or res.unexpected_keys:
+        print(f"[lavender_amd] {what}: missing keys {sorted(res.missing_keys)}; unexpected keys {sorted(res.unexpected_keys)}")
+    return res

@@ -120,6 +120,38 @@ __global__ __launch_bounds__(256) void scale_bf16_kernel(long n8, bf16_t* x, con
     }
 }
 
+// x *= scalar[0] with the scalar read ON THE DEVICE (an upstream autograd gradient): no host round trip; a scalar of
+// exactly 1 (loss = ls_mtm + ls_vtm, main_pretrain_mlm.py:163) leaves after one load per thread
+template <bool F32>
+__global__ __launch_bounds__(256) void scale_scalar_kernel(long n8, void* x, const float* scalar) {
+    const float s = scalar[0];
+    if (s == 1.f) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        if (F32) {
+            float4* p = (float4*)x + 2 * i;
+            float4 a = p[0], b = p[1];
+            a.x *= s; a.y *= s; a.z *= s; a.w *= s; b.x *= s; b.y *= s; b.z *= s; b.w *= s;
+            p[0] = a; p[1] = b;
+        } else {
+            float v[8];
+            uint4 u = *((uint4*)x + i);
+            unpack8(u, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= s;
+            *((uint4*)x + i) = pack8(v);
+        }
+    }
+}
+
+extern "C" int lav_scale_by_scalar(void* stream, long n_elems, void* x, int x_is_f32, const float* scalar_dev) {
+    LAV_REQUIRE(n_elems > 0 && n_elems % 8 == 0 && x && scalar_dev, "lav_scale_by_scalar: bad arguments (n must be a multiple of 8)");
+    long n8 = n_elems / 8;
+    int grid = (int)((n8 + 255) / 256 > 8192 ? 8192 : (n8 + 255) / 256);
+    if (x_is_f32) hipLaunchKernelGGL(scale_scalar_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n8, x, scalar_dev);
+    else hipLaunchKernelGGL(scale_scalar_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n8, x, scalar_dev);
+    return lav_check_launch("lav_scale_by_scalar");
+}
+
 extern "C" int lav_scale_by_count(void* stream, long n_elems, void* x_bf16, const float* loss_sum, float gscale) {
     LAV_REQUIRE(n_elems > 0 && n_elems % 8 == 0 && x_bf16, "lav_scale_by_count: bad arguments");
     long n8 = n_elems / 8;
@@ -258,7 +290,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 p = ((float4*)a.p)[i], g = ((const float4*)a.g)[i], m = ((float4*)a.m)[i], v = ((float4*)a.v)[i];
         float pp[4] = {p.x, p.y, p.z, p.w}, gg[4] = {g.x, g.y, g.z, g.w}, mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
-        const int gi = a.grp ? a.grp[i >> 4] & 3 : 0;
+        const int gv = a.grp ? a.grp[i >> 4] : 0;
+        // bit 2: a parameter that never receives a gradient on this path (emb_task, enc_img.emb_odr).  In the reference its
+        // .grad is None and torch.optim.AdamW skips the tensor entirely -- no weight decay, no moment update
+        if (gv & 4) continue;
+        const int gi = gv & 3;
         const float lr = a.lr[gi], wd = a.wd[gi];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

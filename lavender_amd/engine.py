@@ -594,17 +594,17 @@ class CrossEntropyFn(torch.autograd.Function):
         buf = ctx.grad_buf
         if buf is None:
             return None, None, None
-        # d(loss)/d(logits) already sits in `buf` for an upstream gradient of 1, which is what
-        # loss = ls_mtm + ls_vtm (main_pretrain_mlm.py:163) delivers.  A different upstream scale (e.g. a
-        # GradScaler) is honoured when CrossEntropyFn.assume_unit_grad is False (costs one host sync).
+        # d(loss)/d(logits) sits in `buf` for an upstream gradient of 1 (loss = ls_mtm + ls_vtm, main_pretrain_mlm.py:163).
+        # Any other upstream scale (gradient accumulation loss / k, loss weights, a GradScaler) is applied by a kernel that
+        # reads the scalar on the device -- no host sync; an upstream gradient of exactly 1 costs one load per thread.
         if not CrossEntropyFn.assume_unit_grad:
-            gv = float(g)
-            if gv != 1.0:
-                if buf.dtype == torch.float32:
-                    buf.mul_(gv)
-                else:
-                    K.scale_by_count(buf, buf.shape[0] * buf.stride(0), None, gv)
+            n = buf.shape[0] * buf.stride(0)
+            if n % 8 == 0:
+                K.scale_by_scalar(buf, n, g.reshape(1).float())
+            else:                                          # tiny fp32 score matrices whose size is not a multiple of 8
+                buf.mul_(g)
         return buf, None, None
 
 
-CrossEntropyFn.assume_unit_grad = True
+# Set to True only by a caller that guarantees an upstream gradient of exactly 1 (skips the scale launch above).
+CrossEntropyFn.assume_unit_grad = False

@@ -318,6 +318,11 @@ def scale_by_count(x, n_elems, loss_sum, gscale):
     L.check(L.lib.lav_scale_by_count(_s(), int(n_elems), _p(x), _p(loss_sum), float(gscale)), "lav_scale_by_count")
 
 
+def scale_by_scalar(x, n_elems, scalar_dev):
+    """x *= scalar_dev[0] (device scalar, no host sync; exactly 1 is a no-op)."""
+    L.check(L.lib.lav_scale_by_scalar(_s(), int(n_elems), _p(x), int(x.dtype == torch.float32), _p(scalar_dev)), "lav_scale_by_scalar")
+
+
 def pair_score_fwd(h, n, F, w16, bias, inv_temp, O):
     """(n, F) hidden rows -> (n // O, O) fp32 logits."""
     buf = torch.empty((n // O, O), dtype=torch.float32, device=h.device)

@@ -14,7 +14,7 @@ import torch.nn as nn
 from . import engine as E
 from . import hip as K
 from .arena import ParamArena
-from .bert import BertConfigLite, BertEmbeddings, BertEncoder, load_hf_state
+from .bert import BertConfigLite, BertEmbeddings, BertEncoder, load_hf_into, load_hf_state
 from .video_swin import LayerNorm, Linear, get_vidswin_model
 
 
@@ -72,7 +72,7 @@ class EncTxt(nn.Module):
         self.size_vocab = cfg.vocab_size
         sd = load_hf_state(args.txt_backbone, [("bert.embeddings.", "emb_txt."), ("embeddings.", "emb_txt.")])
         if sd:
-            self.load_state_dict({k: v for k, v in sd.items() if "position_ids" not in k and "token_type_ids" not in k}, strict=False)
+            load_hf_into(self, sd, "text embeddings (HF checkpoint)")
         self._arena_of = None
 
     def forward(self, txt, mask_txt=None, token_type_ids=None, position_ids=None, attn_mask_type="full"):
@@ -96,7 +96,7 @@ class LAVENDER_Base(nn.Module):
         if not getattr(args, "fusion_encoder_rand_init", False):
             sd = load_hf_state(args.fusion_encoder, [("bert.encoder.", "")])
             if sd:
-                self.trsfr.load_state_dict(sd, strict=False)
+                load_hf_into(self.trsfr, sd, "fusion encoder (HF checkpoint)")
         self.mask_ext = self._extended_mask
         self.enc_img = EncVideo(args, self.hidden_size)
         self.use_checkpoint = bool(getattr(args, "use_checkpoint", False))   # 288 GB HBM: activations are kept, no CPU offload

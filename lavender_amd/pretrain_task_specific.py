@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import engine as E
 from .agent import Agent_Base
-from .bert import BertConfigLite, BertOnlyMLMHead, load_hf_state
+from .bert import BertConfigLite, BertOnlyMLMHead, load_hf_into, load_hf_state
 from .model import LAVENDER_Base
 from .pretrain_mlm import masking, vtm_pairs
 
@@ -43,7 +43,7 @@ class LAVENDER_Pretrain(LAVENDER_Base):
         self.fc_mtm = BertOnlyMLMHead(cfg)
         sd = load_hf_state(args.tokenizer, [("cls.", "")])
         if sd:
-            self.fc_mtm.load_state_dict(sd, strict=False)
+            load_hf_into(self.fc_mtm, sd, "MLM head (HF checkpoint)")
 
     def arena(self):
         a = super().arena()

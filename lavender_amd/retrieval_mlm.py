@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from .agent import Agent_Base
-from .bert import BertConfigLite, BertOnlyMLMHead, load_hf_state
+from .bert import BertConfigLite, BertOnlyMLMHead, load_hf_into, load_hf_state
 from .model import LAVENDER_Base
 
 
@@ -25,7 +25,7 @@ class LAVENDER_Retrieval_MLM(LAVENDER_Base):
         self.fc_mtm = BertOnlyMLMHead(cfg)
         sd = load_hf_state(args.tokenizer, [("cls.", "")])
         if sd:
-            self.fc_mtm.load_state_dict(sd, strict=False)
+            load_hf_into(self.fc_mtm, sd, "MLM head (HF checkpoint)")
         self.task_tok2id = {"vtm": 0, "mc": 1, "oe": 2, "cap": 3}
         self.emb_task = nn.Parameter(0.02 * torch.randn(10, self.hidden_size))
 

@@ -49,12 +49,35 @@ def _worker(rank, world, port, q):
     ok &= red.stage_ranges == {0: (32000, 38400), 1: (38400, 51200)}
     for f in arena.listeners:
         f("swin_stage1_grads_final")
-        f("swin_stage1_grads_final")                          # a repeated event must not reduce twice
+        try:
+            f("swin_stage1_grads_final")                      # a repeated event in one step must fail loudly (two backwards / two enc_img calls)
+            ok = False
+        except RuntimeError:
+            pass
     mid = arena.grad.clone()
     ok &= bool(torch.allclose(mid[38400:51200], expect[38400:51200], atol=1e-6)) and bool(torch.equal(mid[32000:38400], local[32000:38400]))
     red.finish()
     ok &= bool(torch.allclose(arena.grad, expect, atol=1e-6))
     ok &= red.world == world
+    # gradient accumulation: the non-final backward raises the same events, which must be ignored; finish() exchanges everything
+    arena.grad.copy_(local)
+    red.begin_step(last_micro_step=False)
+    for f in arena.listeners:
+        f("fusion_grads_final")
+        f("fusion_grads_final")
+    ok &= bool(torch.equal(arena.grad, local))
+    red.finish()
+    ok &= bool(torch.allclose(arena.grad, expect, atol=1e-6))
+    # begin_step on an unfinished exchange is an error
+    red.begin_step()
+    for f in arena.listeners:
+        f("fusion_grads_final")
+    try:
+        red.begin_step()
+        ok = False
+    except RuntimeError:
+        pass
+    red.finish()
     q.put((rank, ok))
     dist.destroy_process_group()
 
@@ -70,3 +93,87 @@ def test_arena_reducer_world2():
     for p in ps:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---- ZeRO-1 (args.deepspeed): reduce-scatter + sharded AdamW + all-gather of the bf16 working copy ---------------------------
+class _MockArena:
+    """The slice of lavender_amd.arena.ParamArena the reducers use, with the fused AdamW kernel restated on the CPU."""
+
+    def __init__(self, total, rank):
+        slack = 4096
+        g = torch.Generator().manual_seed(1234)
+        self.total = total
+        self.master = (torch.randn(total, generator=g) * 0.1 + float(rank))       # rank-dependent: the broadcast must fix it
+        self.half_full = torch.zeros(total + slack, dtype=torch.bfloat16)
+        self.half = self.half_full[:total]
+        self.grad_full = torch.zeros(total + slack)
+        self.grad = self.grad_full[:total]
+        self.names, self.listeners = [], []
+        self.m = self.v = None
+        self.transposed_syncs = 0
+
+    def sync_half(self):
+        self.half.copy_(self.master.bfloat16())
+
+    def sync_transposed(self):
+        self.transposed_syncs += 1
+
+    def adamw_step(self, lr4, wd4, step, max_norm, grad_div, betas, eps, shard=None, sum_gradsq=None):
+        from oracle import lavender_ref as R
+        lo, hi = (0, self.total) if shard is None else shard
+        if self.m is None:
+            self.m, self.v = torch.zeros(hi - lo), torch.zeros(hi - lo)
+        sq = (self.grad[lo:hi].double() ** 2).sum().float().reshape(1)
+        if sum_gradsq is not None:
+            sum_gradsq(sq)
+        coef = 1.0 / grad_div
+        c = max_norm / (sq.sqrt().item() / grad_div + 1e-6)
+        if max_norm > 0 and c < 1:
+            coef *= c
+        p, self.m, self.v = R.adamw_step(self.master[lo:hi], self.grad[lo:hi] * coef, self.m, self.v, step, lr4[0], wd4[0])
+        self.master[lo:hi] = p
+        self.half[lo:hi] = p.bfloat16()
+
+
+def _zero_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lavender_amd.dp import ArenaReducer, ZeroOneReducer
+    total = 64 * 333                                            # not a multiple of world * 64: the last shard is short
+    lr4, wd4 = [1e-2] * 4, [1e-3] * 4
+    outs = {}
+    for kind in ("ddp", "zero1"):
+        arena = _MockArena(total, rank)
+        model = types.SimpleNamespace(arena=lambda a=arena: a)
+        red = (ZeroOneReducer if kind == "zero1" else ArenaReducer)(model)
+        for step in (1, 2):
+            arena.grad_full.zero_()
+            arena.grad.copy_(torch.randn(total, generator=torch.Generator().manual_seed(100 * step + rank)))
+            red.begin_step()
+            for f in arena.listeners:
+                f("fusion_grads_final")                         # ZeRO-1 ignores the overlap events
+            red.finish()
+            red.optimizer_step(arena, lr4, wd4, step, 1.0, (0.9, 0.98), 1e-8)
+        red.gather_master()
+        outs[kind] = (arena.master.clone(), arena.half.clone(), arena.m.numel(), arena.transposed_syncs)
+    (m0, h0, n0, _), (m1, h1, n1, ts) = outs["ddp"], outs["zero1"]
+    shard = ((total + world - 1) // world + 63) // 64 * 64
+    ok = bool(torch.allclose(m0, m1, atol=1e-6)) and bool(torch.equal(h0, h1))      # ZeRO-1 == replicated AdamW
+    ok &= n0 == total and n1 == min(shard, total - min(rank * shard, total)) and ts == 2   # optimizer state for the own shard only
+    q.put((rank, ok, float(m1.double().sum())))
+    dist.destroy_process_group()
+
+
+def test_zero1_matches_replicated_adamw_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_zero_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert [r[:2] for r in res] == [(0, True), (1, True)]
+    assert res[0][2] == res[1][2]                               # identical parameters on both ranks after gather_master()

@@ -31,7 +31,7 @@ def _rank_grads(rank, agent, m):
     return m.arena().grad.clone()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, zero=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     torch.cuda.set_device(0)
@@ -41,9 +41,9 @@ def _worker(rank, world, port, q):
     torch.manual_seed(100 + rank)                       # different initial weights: the broadcast must fix that
     m = LA.LAVENDER_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3), Tok()).cuda()
     m.arena()
-    agent = LA.Agent_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3), m)
+    agent = LA.Agent_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3, deepspeed=zero), m)
     agent.prepare_dist_model()
-    assert agent.dp is not None and agent.dp.world == world
+    assert agent.dp is not None and agent.dp.world == world and agent.dp.zero_stage == (1 if zero else 0)
     w0 = m.arena().master.clone()
     # reference: both ranks' local gradients computed in this process with the reducer detached
     listeners, m.arena().listeners = m.arena().listeners, []
@@ -51,22 +51,28 @@ def _worker(rank, world, port, q):
     g_other = _rank_grads(1 - rank, agent, m)
     m.arena().listeners = listeners
     # the real thing: backward (fusion-side ranges are all-reduced while the video backward still runs) + finish()
+    agent.dp.begin_step()
     _rank_grads(rank, agent, m)
     agent.dp.finish()
     g_sum = m.arena().grad.clone()
-    rel = ((g_mine + g_other) - g_sum).norm() / g_sum.norm()
-    m.arena().grad.copy_(g_sum)
-    agent.optzr.step(max_norm=1.0, grad_div=float(world))
+    lo, hi = (agent.dp.lo, agent.dp.hi) if zero else (0, g_sum.numel())           # ZeRO-1: only the own shard holds the sum
+    rel = ((g_mine + g_other)[lo:hi] - g_sum[lo:hi]).norm() / g_sum[lo:hi].norm()
+    agent.optzr.step(max_norm=1.0, dp=agent.dp)
+    if zero:
+        assert m.arena().m.numel() == hi - lo                                     # optimizer state for the own shard only
+    agent.dp.gather_master()
     torch.cuda.synchronize()
-    q.put((rank, float(rel), float(w0.double().sum()), float(m.arena().master.double().sum())))
+    w1 = m.arena().master
+    same16 = bool(torch.equal(m.arena().half.float(), w1.bfloat16().float()))     # bf16 working copy == rounded masters everywhere
+    q.put((rank, float(rel), float(w0.double().sum()), float(w1.double().sum()), float((w1.double() ** 2).sum()), same16))
     dist.destroy_process_group()
 
 
-def test_two_ranks_allreduce_and_replica_consistency():
+def _run_two_ranks(zero):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1000)
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 1000) + (37 if zero else 0)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, zero)) for r in range(2)]
     for p in ps:
         p.start()
     import queue as _queue
@@ -85,10 +91,24 @@ def test_two_ranks_allreduce_and_replica_consistency():
     res = sorted(res)
     for p in ps:
         p.join(timeout=60)
-    (r0, rel0, w0a, w0b), (r1, rel1, w1a, w1b) = res
+    (r0, rel0, w0a, w0b, s0, h0), (r1, rel1, w1a, w1b, s1, h1) = res
     assert rel0 < 2e-2 and rel1 < 2e-2, (rel0, rel1)            # sum of per-rank grads (atomics: order-dependent fp32 rounding)
     assert w0a == w1a                                            # broadcast from rank 0
-    assert w0b == w1b and w0b != w0a                             # identical update on both replicas
+    assert w0b == w1b and w0b != w0a and s0 == s1                # identical parameters on both replicas after the step
+    assert h0 and h1
+    return w0b, s0
+
+
+def test_two_ranks_allreduce_and_replica_consistency():
+    _run_two_ranks(False)
+
+
+def test_zero1_two_ranks_matches_replicated_step():
+    """args.deepspeed (ZeRO-1: reduce-scatter, AdamW on the own shard with sharded m / v, all-gather of the bf16 copy) lands on
+    the same parameters as the replicated step (the two differ only in the summation order of the clip norm)."""
+    w_ddp, s_ddp = _run_two_ranks(False)
+    w_z, s_z = _run_two_ranks(True)
+    assert abs(w_ddp - w_z) <= 1e-6 * max(1.0, abs(w_ddp)) and abs(s_ddp - s_z) <= 1e-6 * s_ddp, (w_ddp, w_z, s_ddp, s_z)
 
 
 def _rccl_worker(port, q):

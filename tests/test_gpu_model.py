@@ -169,6 +169,8 @@ def test_training_steps_reduce_loss_and_respect_contract():
     b.update(agent.masking(b["txt"], b["mask"]))
     batch = agent.prepare_batch(b)
     assert batch["_n_mtm"] == int((b["ans_mtm"] != -1).sum())
+    frozen0 = (m.emb_task.detach().clone(), m.enc_img.emb_odr.detach().clone())
+    decayed0 = m.enc_img.emb_len.detach().clone()
     losses = []
     for i in range(12):
         np.random.seed(i)
@@ -179,6 +181,9 @@ def test_training_steps_reduce_loss_and_respect_contract():
     assert abs(losses[0] - 2 * np.log(8192)) < 1.5
     assert losses[-1] < losses[0] - 1.0
     assert float(m.emb_task.grad.abs().max()) == 0.0 and float(m.enc_img.emb_odr.grad.abs().max()) == 0.0
+    # grad None in the reference => torch AdamW skips these tensors entirely (no weight decay): they must not move
+    assert torch.equal(m.emb_task.detach(), frozen0[0]) and torch.equal(m.enc_img.emb_odr.detach(), frozen0[1])
+    assert not torch.equal(m.enc_img.emb_len.detach(), decayed0)
     r = agent.step(batch, False)                                   # eval branch: accuracies, logits preserved
     assert 0.0 <= r["mtm"] <= 1.0 and 0.0 <= r["vtm"] <= 1.0
 
@@ -219,3 +224,26 @@ def test_base_12l_forward_and_loss_vs_oracle():
         assert d.max() < 3e-2 and d.mean() < 5e-3 and agree >= 0.97 and margin < 3e-2
     print("loss", ls_mtm.item(), ls_vtm.item(), "oracle", l1.item(), l2.item())
     assert abs(ls_mtm.item() - l1.item()) < 1e-2 and abs(ls_vtm.item() - l2.item()) < 1e-2
+
+
+def test_upstream_gradient_scale_is_honoured_without_host_sync():
+    """loss / k (gradient accumulation), loss weights or a GradScaler put a factor other than 1 in front of the loss: the stored
+    d(loss)/d(logits) is multiplied by the DEVICE scalar (lav_scale_by_scalar), so every gradient scales with it."""
+    from tests.helpers import build_filled_model
+    from lavender_amd.agent import CrossEntropyIgnore
+    R, P, batch, bc = _oracle_case("micro", "micro", 2)
+    m = build_filled_model("micro", "micro", 2).eval()
+    lf = CrossEntropyIgnore()
+    grads = []
+    for k in (1.0, 0.25):
+        m.arena().zero_grad()
+        np.random.seed(88)
+        out = m(_to_cuda(batch))
+        ls = lf(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten()) * k + \
+            lf(out["out_vtm"].flatten(0, 1), out["ans_vtm"].flatten(), count=out["ans_vtm"].shape[0]) * k
+        ls.backward()
+        torch.cuda.synchronize()
+        grads.append(m.arena().grad.clone())
+    rel = ((grads[1] - 0.25 * grads[0]).norm() / (0.25 * grads[0]).norm()).item()
+    print("upstream 0.25 vs 1.0: relative difference of the scaled gradients", rel)
+    assert rel < 2e-2 and grads[1].norm() > 0

@@ -206,3 +206,48 @@ def test_checkpoint_contract_round_trip(tmp_path):
     assert torch.equal(c.fc[1].weight, fc0) and torch.equal(c.trsfr.layer[0].output.dense.weight, a.trsfr.layer[0].output.dense.weight)
     c.load_ckpt(str(tmp_path / "does_not_exist.pt"))
     c.load_ckpt('')
+
+
+def test_bench_spawns_its_own_ranks_and_refuses_a_wrong_world_size():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (not label a 1-rank run as N GPUs), and a
+    launcher world size that contradicts --gpus must fail loudly.  --selftest-launch stops after the rendezvous + all-reduce
+    (gloo on this GPU-less container)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"], capture_output=True, text=True,
+                       timeout=240, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-400:], r.stderr[-400:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_observed"] == 2
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"], capture_output=True, text=True,
+                       timeout=120, env={**env, "WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_hf_checkpoint_loader_renames_legacy_layernorm_keys_and_ties_the_decoder(tmp_path):
+    """Stock bert-base-uncased files name LayerNorm parameters gamma / beta and omit the tied cls.predictions.decoder.weight;
+    `from_pretrained` (model.py:100-102, main_pretrain_mlm.py:46-48) fixes both up, so must load_hf_state."""
+    from lavender_amd.bert import BertConfigLite, BertEmbeddings, BertOnlyMLMHead, load_hf_into, load_hf_state
+    cfg = BertConfigLite(vocab_size=50, hidden_size=64, num_attention_heads=1, intermediate_size=128, max_position_embeddings=16)
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: torch.randn(*s, generator=g)
+    sd = {"bert.embeddings.word_embeddings.weight": r(50, 64), "bert.embeddings.position_embeddings.weight": r(16, 64),
+          "bert.embeddings.token_type_embeddings.weight": r(2, 64), "bert.embeddings.LayerNorm.gamma": r(64),
+          "bert.embeddings.LayerNorm.beta": r(64), "bert.embeddings.position_ids": torch.arange(16)[None],
+          "cls.predictions.bias": r(50), "cls.predictions.transform.dense.weight": r(64, 64), "cls.predictions.transform.dense.bias": r(64),
+          "cls.predictions.transform.LayerNorm.gamma": r(64), "cls.predictions.transform.LayerNorm.beta": r(64)}
+    torch.save(sd, tmp_path / "pytorch_model.bin")
+    emb = BertEmbeddings(cfg)
+    res = load_hf_into(emb, load_hf_state(str(tmp_path), [("bert.embeddings.", "")]), "embeddings")
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(emb.LayerNorm.weight.data, sd["bert.embeddings.LayerNorm.gamma"])
+    assert torch.equal(emb.LayerNorm.bias.data, sd["bert.embeddings.LayerNorm.beta"])
+    head = BertOnlyMLMHead(cfg)
+    res = load_hf_into(head, load_hf_state(str(tmp_path), [("cls.", "")]), "head")
+    assert not res.missing_keys
+    assert torch.equal(head.predictions.decoder.weight.data, sd["bert.embeddings.word_embeddings.weight"])
+    assert torch.equal(head.predictions.transform.LayerNorm.weight.data, sd["cls.predictions.transform.LayerNorm.gamma"])
