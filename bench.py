@@ -121,6 +121,10 @@ def main():
                     help="opt-in side measurement (NOT the contract line): MLM head + loss on the supervised positions only")
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="side measurement at --gpus 1: join a 1-rank RCCL process group and attach the gradient reducer (what the "
+                         "overlap bookkeeping and the comm-stream events cost when there is nobody to talk to)")
+    ap.add_argument("--zero1", action="store_true", help="side measurement: args.deepspeed = True (ZeRO-1 reducer)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_only:
@@ -153,6 +157,10 @@ def main():
         dist.init_process_group(backend="nccl" if use_cuda else "gloo", init_method="env://")
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus says {a.gpus}")
+    elif a.force_dp and not a.selftest_launch:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
     if a.selftest_launch:
         seen = 1
         if world > 1:
@@ -179,7 +187,7 @@ def main():
     args = EasyDict(vis_backbone_size=a.size, size_img=S, vis_backbone_init="random", kinetics=600, txt_backbone=cfg,
                     txt_backbone_embed_only=True, fusion_encoder=cfg, fusion_encoder_rand_init=True, use_checkpoint=False,
                     size_patch=32, size_batch=B, tokenizer=cfg, enable_task_token=False, enable_prompt=False, temp=0.05,
-                    lr=2e-5, decay=1e-3, max_iter=10000, max_grad_norm=1.0, deepspeed=False, vis_backbone_lr_mul=1.0,
+                    lr=2e-5, decay=1e-3, max_iter=10000, max_grad_norm=1.0, deepspeed=bool(a.zero1), vis_backbone_lr_mul=1.0,
                     dataset=["synthetic"], logging_steps=20, path_output="/tmp/lav_bench", task="pretrain", seed=88,
                     loss_aware_head=bool(a.loss_aware_head))
 
@@ -195,6 +203,9 @@ def main():
     model.arena()
     agent = (LA.Agent_Retrieval_MLM if retrieval else LA.Agent_Pretrain_MLM)(args, model)
     agent.prepare_dist_model()
+    if a.force_dp and world == 1:
+        from lavender_amd.dp import ArenaReducer, ZeroOneReducer
+        agent.dp = (ZeroOneReducer if a.zero1 else ArenaReducer)(model)
     nparam = sum(p.numel() for p in model.parameters())
 
     # synthetic batches resident in HBM, labels built like the reference does (host masking, then H2D)
@@ -314,6 +325,10 @@ def main():
         fstep = 3.0 * flops_per_sample(**{"base": {}, "tiny": dict(E=96, depths=(2, 2, 6, 2)),
                                           "large": dict(E=192, win=(8, 12, 12))}.get(a.size, {}), layers=a.layers, S=S, X=X,
                                        n_seq=B if retrieval else 1 + min(B, 4))
+        if a.force_dp:
+            what_dp = "SIDE CASE 1-rank RCCL reducer attached -- "
+        else:
+            what_dp = ""
         what = {"cfg2": "cfg2: ", "cfg4": "cfg4 (parity/bench side case): ", "cfg5": "cfg5 retrieval B x B pairing (side case): "}[a.workload]
         if a.loss_aware_head:
             what = "SIDE CASE loss-aware head (labelled positions only, not the reference's full-logit outputs) -- " + what
@@ -321,7 +336,7 @@ def main():
                "unit": "samples/s", "n_gpus": world, "world_size_observed": (dist.get_world_size() if world > 1 else 1),
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "ms_per_step_median_hip_events": round(ms_median, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"{what}Swin-{a.size}-K600-22k + {a.layers}-layer fusion + MLM head, "
+               "config": {"workload": f"{what_dp}{what}Swin-{a.size}-K600-22k + {a.layers}-layer fusion + MLM head, "
                                       f"{'main_retrieval_mlm' if retrieval else 'main_pretrain_mlm'} path, "
                                       f"fwd+bwd+clip+AdamW, dropout 0.1 / drop-path 0.2 on",
                           "per_gpu_batch": B, "global_batch": B * world, "frames": T, "size_img": S, "size_txt": X,

@@ -74,6 +74,10 @@ typedef struct lav_gemm_epilogue {
 
 int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                   void* C, long ldc, const lav_gemm_epilogue* epi, int splits);
+/* Tuning / probe hook: selects between kernel variants of lav_gemm_bf16 at run time (within-process A/B measurements);
+ * which 0 = the ping-pong 256x256x32 kernel for large NT problems (value 0 / 1).  Returns the previous value, -1 for an
+ * unknown selector.  Results are identical up to fp32 summation order. */
+int lav_gemm_select(int which, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension (nn.LayerNorm at video_swin.py:209,245,282,399-403,476-478;

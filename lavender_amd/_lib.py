@@ -58,6 +58,7 @@ _SIGS = {
     "lav_last_error": (C.c_char_p, []),
     "lav_abi_version": (i32, []),
     "lav_gemm_bf16": (i32, [vp, i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, P(GemmEpilogue), i32]),
+    "lav_gemm_select": (i32, [i32, i32]),
     "lav_layernorm_fwd": (i32, [vp, i32, i32, vp, i64, P(LnGather), vp, vp, f32, vp, i64, vp, vp, P(LnF32)]),
     "lav_layernorm_bwd": (i32, [vp, i32, i32, vp, i64, vp, i64, P(LnGather), vp, vp, vp, vp, i64, vp, i64, vp, vp,
                                 P(LnBwdExtra)]),

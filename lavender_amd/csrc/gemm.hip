@@ -10,6 +10,7 @@
 // epilogue (bias / GELU / dropout / drop-path scale / residual / column sums) runs on 8-wide row
 // chunks with 16-byte global accesses.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include "../../include/lavender_hip.h"
 
@@ -907,6 +908,383 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
 template <bool AKC, bool BKC, unsigned F = EF_ALL>
 __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 8>(g); }
 
+// ------------------------------------------------------------------------------------------------------
+// Ping-pong 256x256x32 kernels.  8 waves in two groups of four -- group g = wave >> 2 owns rows [128 g, 128 g + 128) of
+// the tile, wave & 3 its 64-column strip -- so every SIMD hosts ONE wave of each group (waves w and w + 4 land on the
+// same SIMD).  The groups run the same READ(t) / COMPUTE(t) sequence ONE barrier apart: while a group's waves issue
+// their 16 v_mfma_f32_32x32x16_bf16 of k-tile t (pure register work, 512 cycles), the partner waves on the same SIMDs
+// read the fragments of their next k-tile from LDS and issue the direct-to-LDS loads of the tile three ahead.  The
+// fragment reads are therefore off the matrix pipe's critical path -- what the weight-gradient (TN) layout needs: both
+// of its operands are contraction-strided and go through ds_read_b64_tr_b16, twice the LDS instructions of the
+// K-contiguous layout (measured: the 2-phase TN kernel is LDS-ISSUE bound at ~600 TFLOP/s, half the NT rate).
+// k-tiles of 32 in a ring of four 32 KB stages: a stage is refilled two barriers after its last read and has ~4 steps
+// to land, waited for with a COUNTED vmcnt.
+//   NT stage: [256 rows][64 B] per operand, 16-byte slot s of row r stored at s ^ ((r >> 2) & 3) (the sixteen rows one
+//             ds_read_b128 lane group touches fall on sixteen distinct bank slots).
+//   TN stage: [32 k][256 n] per operand, 512-byte k-rows, 32-byte chunk c of row k stored at c ^ skey(k) (as above).
+// Measured (tools/gemm_pp_ablate.py): per 16-MFMA step 364 ns with MFMAs + fragment reads only, ~550 ns with the NT
+// refills (64-byte row pieces: 27 GB/s per CU) -- the per-CU L2 -> LDS stream, not the matrix pipe or the LDS, is what
+// paces a 256x256 tile, which is why the NT layout stays on the 2-phase kernel above (128-byte row pieces, 34 GB/s per CU).
+// ------------------------------------------------------------------------------------------------------
+#define PP_BK 32
+#define PP_STAGE 32768
+#define PP_NS 4
+#define PP_LDS HUGE_LDS
+
+template <bool TN>
+__device__ __forceinline__ void pp_issue(char* st, const GemmArgs& g, int m0, int n0, int k0, int wave, int lane) {
+    if (TN) {
+        huge_glds_strided<2>(st, g.A, g.lda, m0, g.M, k0, wave, lane);            // [32 k][256 m]: 16 pieces, 2 per wave
+        huge_glds_strided<2>(st + 16384, g.B, g.ldb, n0, g.N, k0, wave, lane);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = wave * 2 + i;                        // 1-KB piece = 16 rows x 64 B
+        const int rt = t * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((lane >> 4) & 3);   // logical slot that lands on physical slot lane & 3 of row rt
+        const bf16_t* sa = g.A + (long)min(m0 + rt, g.M - 1) * g.lda + k0 + slot * 8;
+        const bf16_t* sb = g.B + (long)min(n0 + rt, g.N - 1) * g.ldb + k0 + slot * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                         (__attribute__((address_space(3))) void*)(st + t * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                         (__attribute__((address_space(3))) void*)(st + 16384 + t * 1024), 16, 0, 0);
+    }
+}
+
+// 32x32x16 operand fragment (32 rows/cols x 16 k) of a contraction-strided tile [k][256], 512-byte k-rows: byte offset of
+// this lane's first transposing read inside the tile (k-rows k .. k+3); the second read (k+4 .. k+7) is 2048 bytes further
+__device__ __forceinline__ int pp_frag_strided_off(int blk32, int ks2, int lane) {
+    const int i = lane & 15, q = lane >> 4, r = i >> 2, c = i & 3;
+    const int t16 = blk32 * 2 + (q & 1);
+    const int k = ks2 * 16 + 8 * (q >> 1) + r;
+    return k * 512 + ((t16 ^ skey(k)) << 5) + c * 8;
+}
+// ds_read_b64_tr_b16 as inline asm: the builtin makes hipcc drain EVERY outstanding direct-to-LDS load (s_waitcnt vmcnt(0))
+// in front of the reads, which serialises the refill pipeline.  The destination is valid only after the caller's own
+// s_waitcnt lgkmcnt(0) (+ sched_barrier) -- nothing may touch it before.
+__device__ __forceinline__ s16x4 tr_read_async(unsigned lds_addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));
+    return v;
+}
+__device__ __forceinline__ s16x4 tr_read_async_2k(unsigned lds_addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(v) : "v"(lds_addr));
+    return v;
+}
+__device__ __forceinline__ bf16x8 join_frag(s16x4 lo, s16x4 hi) {
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+// one of the four 1-KB pieces a wave contributes to a stage: p = 0, 1 operand A, p = 2, 3 operand B
+template <bool TN>
+__device__ __forceinline__ void pp_issue_piece(char* st, const GemmArgs& g, int m0, int n0, int k0, int wave, int lane, int p) {
+    const int t = wave * 2 + (p & 1);
+    const bool isb = p >= 2;
+    const bf16_t* P = isb ? g.B : g.A;
+    const long ld = isb ? g.ldb : g.lda;
+    const int o0 = isb ? n0 : m0, O = isb ? g.N : g.M;
+    const bf16_t* src;
+    if (TN) {
+        const int krow = t * 2 + (lane >> 5);
+        const int ch = ((lane & 31) >> 1) ^ skey(krow);
+        const int col = min(o0 + ch * 16 + (lane & 1) * 8, ((O + 7) & ~7) - 8);
+        src = P + (long)(k0 + krow) * ld + col;
+    } else {
+        const int rt = t * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((lane >> 4) & 3);
+        src = P + (long)min(o0 + rt, O - 1) * ld + k0 + slot * 8;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(st + (isb ? 16384 : 0) + t * 1024), 16, 0, 0);
+}
+
+// TN refill piece as inline asm, scalar base + per-lane 32-bit offset (no per-piece VALU, 4 offset registers per wave in
+// total).  Why asm: with the builtin hipcc knows an LDS-DMA is outstanding and drains it (s_waitcnt vmcnt(0)) in front of
+// every ds_read_b64_tr_b16 -- the transposing read "may alias" -- which serialises the refill pipeline.  Hidden from its
+// scoreboard, the loads are ordered by this kernel's own counted vmcnt + barriers only.
+__device__ __forceinline__ void pp_dma_saddr(unsigned lds_dst, const void* sbase, unsigned voff) {
+    unsigned keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+}
+
+__device__ __forceinline__ void pp_wait_tiles(int rem) {   // s_waitcnt vmcnt(4 * rem): `rem` younger k-tiles stay in flight
+    if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool TN, unsigned F, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int tiles_n = (g.N + 255) / 256, tiles_m = (g.M + BIG_BM - 1) / BIG_BM;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int tot = nwg * g.splits;
+        int q = tot >> 3, r = tot & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int split = bid / nwg;
+    bid -= split * nwg;
+    const int m0 = (bid / tiles_n) * BIG_BM, n0 = (bid % tiles_n) * 256;
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nk = (kend - kbeg) / PP_BK;
+    constexpr int D = PP_NS - 1;                           // prefetch distance in k-tiles
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 fa[4][2], fb[2][2];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    int toa[4][2], tob[2][2];                              // TN: per-lane byte offsets of the first read of each fragment inside a stage
+    if (TN) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) toa[i][s2] = pp_frag_strided_off(grp * 4 + i, s2, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tob[j][s2] = 16384 + pp_frag_strided_off(wn * 2 + j, s2, lane);
+        }
+    }
+    // NT: per-lane LDS offsets of the fragment reads: row (lane & 31) of a 32-row block, logical slot 2 s + (lane >> 5)
+    int lo[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) lo[s2] = (lane & 31) * 64 + ((((2 * s2 + (lane >> 5)) ^ ((lane >> 2) & 3))) << 4);
+    const int abase = grp * 128 * 64, bbase = 16384 + wn * 64 * 64;
+    // TN: bias gradient = row sums of A^T (= column sums of dy), by the wn == 0 waves of the n0 == 0 blocks, on the VALU
+    // from the A fragments they hold anyway (a ones-fragment MFMA would need 64 more accumulator registers per wave)
+    const bool do_rowsum = TN && g.e.rowsum_a != nullptr && n0 == 0 && wn == 0;
+    float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* keep = TN ? g.e.k_keep : nullptr;
+
+    // TN refills: byte offset of this lane's 16 bytes of piece p relative to the first k-row of the tile (clamped columns)
+    unsigned voff[4] = {0, 0, 0, 0};
+    if (TN) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int tp = wave * 2 + (p & 1);
+            const bool isb = p >= 2;
+            const int krow = tp * 2 + (lane >> 5);
+            const int ch = ((lane & 31) >> 1) ^ skey(krow);
+            const int O = isb ? g.N : g.M;
+            const int col = min((isb ? n0 : m0) + ch * 16 + (lane & 1) * 8, ((O + 7) & ~7) - 8);
+            voff[p] = (unsigned)(((long)krow * (isb ? g.ldb : g.lda) + col) * 2);
+        }
+    }
+    // piece p of k-tile tsrc into the stage of k-tile tdst (tdst == tsrc except for the phantom refills past the last tile)
+    auto issue_piece = [&](int tdst, int tsrc, int p) {
+        if constexpr (TN) {
+            const int tp = wave * 2 + (p & 1);
+            const bool isb = p >= 2;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((tdst % PP_NS) * PP_STAGE + (isb ? 16384 : 0) + tp * 1024));
+            const bf16_t* base = (isb ? g.B : g.A) + (long)(kbeg + tsrc * PP_BK) * (isb ? g.ldb : g.lda);
+            pp_dma_saddr(dst, base, voff[p]);
+        } else {
+            pp_issue_piece<false>(smem + (tdst % PP_NS) * PP_STAGE, g, m0, n0, kbeg + tsrc * PP_BK, wave, lane, p);
+        }
+    };
+    auto issue = [&](int t) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) issue_piece(t, t, p);
+    };
+    // drop-path row skipping (TN): 0 = every contraction row of the k-tile belongs to a dropped sample, 1 = all kept,
+    // 2 = the tile straddles a kept and a dropped sample (rows_per_group >= 32: at most one boundary, at row kb).
+    // The keep flags of all samples sit in two 64-bit wave-uniform masks (one ballot each at kernel start) and the sample
+    // of the current k-tile is tracked incrementally: no loads, no divisions in the loop.
+    int kmode = 1;
+    unsigned long long km0 = ~0ull, km1 = ~0ull;
+    int cur_s = 0, nxt_b = 0x7fffffff;                     // sample of the next k-tile to read, first contraction row of the sample after it
+    if (TN && keep) {
+        const int ns = (g.K + g.e.k_rows_per_group - 1) / g.e.k_rows_per_group;
+        km0 = __ballot(lane < ns ? keep[lane] != 0.f : true);
+        km1 = __ballot(lane + 64 < ns ? keep[lane + 64] != 0.f : true);
+        cur_s = kbeg / g.e.k_rows_per_group;
+        nxt_b = (cur_s + 1) * g.e.k_rows_per_group;
+    }
+    auto kept = [&](int sidx) { return ((sidx < 64 ? km0 >> sidx : km1 >> (sidx - 64)) & 1ull) != 0; };
+    auto read = [&](int t) {
+        const char* st = smem + (t % PP_NS) * PP_STAGE;
+        int kb = PP_BK; bool keep0 = true, keep1 = true;
+        if (TN && keep) {
+            const int k0 = kbeg + t * PP_BK;
+            while (k0 >= nxt_b) { ++cur_s; nxt_b += g.e.k_rows_per_group; }
+            kb = nxt_b - k0;
+            keep0 = kept(cur_s);
+            keep1 = kb < PP_BK ? kept(cur_s + 1) : keep0;
+            kmode = (keep0 && keep1) ? 1 : (!keep0 && !keep1) ? 0 : 2;
+            if (kmode == 0) return;
+        }
+        if constexpr (TN) {
+#pragma unroll
+            for (int s2 = 0; s2 < ((DBG & 2) ? (t == 0 ? 2 : 0) : 2); ++s2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j][s2] = join_frag(tr_read(st, tob[j][s2]), tr_read(st, tob[j][s2] + 2048));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i][s2] = join_frag(tr_read(st, toa[i][s2]), tr_read(st, toa[i][s2] + 2048));
+            }
+            if (__builtin_amdgcn_readfirstlane(kmode) == 2) {
+                // rare (one k-tile per sample boundary): zero the dy rows of the dropped sample in the fragments; element e of
+                // fa[.][s2] is contraction row 16 s2 + 8 (lane >> 5) + e
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int kl = 16 * s2 + 8 * (lane >> 5);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        asm volatile("; straddling k-tile" : "+v"(fa[i][s2]));    // not speculatable: keeps the masking out of the common path
+                        union { bf16x8 v; uint16_t h[8]; } u; u.v = fa[i][s2];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) if (!((kl + e) < kb ? keep0 : keep1)) u.h[e] = 0;
+                        fa[i][s2] = u.v;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < ((DBG & 2) ? (t == 0 ? 2 : 0) : 2); ++s2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j][s2] = *(const bf16x8*)(st + bbase + j * 2048 + lo[s2]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i][s2] = *(const bf16x8*)(st + abase + i * 2048 + lo[s2]);
+            }
+        }
+    };
+    int newest = -1;                                       // newest k-tile this wave has issued loads for
+    // Every COMPUTE(t) issues the loads of k-tile t + D between its MFMAs (a direct-to-LDS load costs ~60 cycles of issue among
+    // bare MFMAs, 100-185 next to the fragment reads of a READ segment) -- UNCONDITIONALLY, so that the 16-MFMA sequence stays
+    // one basic block (a branch inside it, or a second copy of it, makes the 16-register accumulator tuples spill).  Past the
+    // end of the contraction the loads re-fetch the last k-tile into a stage nobody reads any more (D tiles per block).
+    auto compute = [&](int trefill) {
+        const int tsrc = trefill < nk ? trefill : nk - 1;
+        if (!(DBG & 1)) newest = trefill;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!(TN && kmode == 0) && !(DBG & 4)) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s2], fb[j][s2], acc[i][j], 0, 0, 0);
+                }
+                if (!(DBG & 1) && (i & 1) == 0) issue_piece(trefill, tsrc, s2 * 2 + (i >> 1));
+            }
+        __builtin_amdgcn_s_setprio(0);
+        if (TN && do_rowsum && kmode != 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    union { bf16x8 v; uint4 u; } u; u.v = fa[i][s2];
+                    float f[8];
+                    unpack8(u.u, f);
+                    rsum[i] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+                }
+        }
+    };
+    // before the barrier that precedes the first read of k-tile tn: this wave's pieces of it have landed
+    auto wait_for = [&](int tn) {
+        if (tn < nk) pp_wait_tiles(newest - tn);
+    };
+
+    // Stage of k-tile t is free once both groups have read it: after the barrier that ends step 2 t + 1.  Group 0 refills it
+    // (with tile t + PP_NS) inside COMPUTE(t + 1) at step 2 t + 3, group 1 inside COMPUTE(t + 1) at step 2 t + 4.
+    const int npro = nk < D ? nk : D;
+    for (int t = 0; t < npro; ++t) issue(t);
+    newest = npro - 1;
+    pp_wait_tiles(npro - 1);
+    __builtin_amdgcn_s_barrier();
+
+    if (grp == 0) {
+        if (nk > 0) read(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t) {
+            compute(t + D);                                  // stage (t - 1) % PP_NS: tile t - 1 was last read at step 2 t - 1
+            wait_for(t + 1);
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < nk) read(t + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the stage may be refilled after the next barrier
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t) {
+            read(t);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            wait_for(t + 1);
+            __builtin_amdgcn_s_barrier();
+            compute(t + D);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // phantom refills: the epilogue reuses the stages
+    __builtin_amdgcn_s_barrier();
+    if (TN && do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = rsum[i] + __shfl_xor(rsum[i], 32, 64);
+            const int row = m0 + grp * 128 + i * 32 + (lane & 31);
+            if (lane < 32 && row < g.M) atomicAdd(g.e.rowsum_a + row, v * g.e.alpha);
+        }
+    }
+    if constexpr (F == EF_TNFLUSH) {
+        // weight-gradient flush: the tile goes through the block-wide fp32 staging in two 128-column halves
+        float* cl = (float*)smem;
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            if ((wn >> 1) == h) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            cl[(grp * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CSTRIDE + (wn & 1) * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+            __syncthreads();
+            gemm_epilogue<BIG_BM, 512, F>(g, cl, m0, n0 + h * 128, split);
+            __syncthreads();
+        }
+        return;
+    } else {
+        // each wave stages its 128 x 64 block through a private LDS slice in two 64-row halves
+        constexpr int WS = 68;
+        float* clw = (float*)smem + wave * (64 * WS);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        clw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WS + j * 32 + (lane & 31)] = acc[h * 2 + i2][j][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            gemm_epilogue<64, 64, F, 8, WS>(g, clw, m0 + grp * 128 + h * 64, n0 + wn * 64, split);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ---- split-K reduction: C[r][c] += sum_s ws[s][tile(r,c)][r % 128][c % 128] -------------------------------------
 // 64 float4 outputs per block x 4 split lanes (each sums every 4th split, loads unrolled for memory parallelism),
 // merged through LDS; one plain read-modify-write of C per output.
@@ -988,6 +1366,16 @@ static const bool lav_gemm_force_small = getenv("LAV_GEMM_SMALL") != nullptr;
 static const bool lav_gemm_no_huge = getenv("LAV_GEMM_NO_HUGE") != nullptr;
 static const int lav_gemm_tn_kind = getenv("LAV_GEMM_TN_KIND") ? atoi(getenv("LAV_GEMM_TN_KIND")) : -1;   // probe hook: 0 = 128x128 only, 1 = at most 256x128, default = largest tile that fits
 static const bool lav_gemm_atomic_flush = getenv("LAV_GEMM_ATOMIC_FLUSH") != nullptr;   // test hook: the old atomic split-K flush
+static bool lav_gemm_pp = getenv("LAV_GEMM_PP") ? atoi(getenv("LAV_GEMM_PP")) != 0 : false;   // ping-pong 256x256x32 kernel
+static bool lav_gemm_pp_tn = getenv("LAV_GEMM_PP_TN") ? atoi(getenv("LAV_GEMM_PP_TN")) != 0 : true;   // ping-pong kernel for the 256x256 weight-gradient tiles
+static int lav_gemm_pp_dbg = 0;                            // ablation builds of the ping-pong kernel (probe only, wrong results): 1 no refills, 2 no fragment reads, 4 no MFMAs
+extern "C" int lav_gemm_select(int which, int value) {    // probe hook (within-process A/B): which 0 = ping-pong kernel on/off; returns the old value
+    int old = -1;
+    if (which == 0) { old = lav_gemm_pp; lav_gemm_pp = value != 0; }
+    if (which == 1) { old = lav_gemm_pp_dbg; lav_gemm_pp_dbg = value; }
+    if (which == 2) { old = lav_gemm_pp_tn; lav_gemm_pp_tn = value != 0; }
+    return old;
+}
 
 extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B,
                              long ldb, void* C, long ldc, const lav_gemm_epilogue* epi, int splits) {
@@ -1070,6 +1458,24 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         else if (fsel == S_BDRO) LAV_LAUNCH_BY_LAYOUT(KERN, S_BDRO, GRID, LDS);                                           \
         else LAV_LAUNCH_BY_LAYOUT(KERN, EF_ALL, GRID, LDS);                                                               \
     } while (0)
+#define LAV_PP_ONE(F_, GRID)                                                                                              \
+    do {                                                                                                                  \
+        static bool attr_done = false;                                                                                    \
+        if (!attr_done) {                                                                                                 \
+            hipFuncSetAttribute((const void*)gemm_pp_kernel<false, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);     \
+            (void)hipGetLastError();                                                                                      \
+            attr_done = true;                                                                                             \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((gemm_pp_kernel<false, F_>), GRID, dim3(512), PP_LDS, s, g);                                          \
+    } while (0)
+#define LAV_LAUNCH_PP(GRID)                                                                                               \
+    do {                                                                                                                  \
+        if (fsel == S_B) LAV_PP_ONE(S_B, GRID);                                                                           \
+        else if (fsel == S_BG) LAV_PP_ONE(S_BG, GRID);                                                                    \
+        else if (fsel == S_GC) LAV_PP_ONE(S_GC, GRID);                                                                    \
+        else if (fsel == S_BDR) LAV_PP_ONE(S_BDR, GRID);                                                                  \
+        else LAV_PP_ONE(S_BDRO, GRID);                                                                                    \
+    } while (0)
     // pick the tile by estimated machine fill: tiles / (rounds * resident slots), weighted by the tile's own efficiency
     auto fill = [](long tiles, long slots, double w) { return w * (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
     const long t_small = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -1081,6 +1487,28 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     if (big && !lav_gemm_no_huge && f_huge >= f_big && f_huge >= f_small) {
         g.k_per_split = K;
         dim3 hgrid((unsigned)t_huge);
+        if (lav_gemm_pp && layout == 0 && fsel != EF_ALL) {
+            if (lav_gemm_pp_dbg) {
+                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+                (void)hipGetLastError();
+                switch (lav_gemm_pp_dbg) {
+                    case 1: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 1>), hgrid, dim3(512), PP_LDS, s, g); break;
+                    case 2: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 2>), hgrid, dim3(512), PP_LDS, s, g); break;
+                    case 3: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 3>), hgrid, dim3(512), PP_LDS, s, g); break;
+                    case 4: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 4>), hgrid, dim3(512), PP_LDS, s, g); break;
+                    case 5: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 5>), hgrid, dim3(512), PP_LDS, s, g); break;
+                    default: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 6>), hgrid, dim3(512), PP_LDS, s, g); break;
+                }
+                return lav_check_launch("lav_gemm_bf16");
+            }
+            LAV_LAUNCH_PP(hgrid);
+            return lav_check_launch("lav_gemm_bf16");
+        }
         LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
         return lav_check_launch("lav_gemm_bf16");
     }
@@ -1131,7 +1559,12 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
                 if (ws) { g.ws = ws; g.ws_tiles = ws_tiles; reduce = true; }
             }
         }
-        if (kind == 2) {
+        if (kind == 2 && lav_gemm_pp_tn && (K % PP_BK) == 0 && (kps % PP_BK) == 0 &&
+            (!g.e.k_keep || (g.e.k_rows_per_group >= PP_BK && (K + g.e.k_rows_per_group - 1) / g.e.k_rows_per_group <= 128))) {
+            static bool a3 = false;
+            if (!a3) { hipFuncSetAttribute((const void*)gemm_pp_kernel<true, EF_TNFLUSH>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS); (void)hipGetLastError(); a3 = true; }
+            hipLaunchKernelGGL((gemm_pp_kernel<true, EF_TNFLUSH>), dim3(((M + BIG_BM - 1) / BIG_BM) * (N / 256) * splits), dim3(512), PP_LDS, s, g);
+        } else if (kind == 2) {
             static bool a2 = false;
             if (!a2) { hipFuncSetAttribute((const void*)gemm_huge_kernel<false, false, EF_TNFLUSH>, hipFuncAttributeMaxDynamicSharedMemorySize, HUGE_LDS); (void)hipGetLastError(); a2 = true; }
             hipLaunchKernelGGL((gemm_huge_kernel<false, false, EF_TNFLUSH>), dim3(((M + BIG_BM - 1) / BIG_BM) * (N / 256) * splits), dim3(512), HUGE_LDS, s, g);
