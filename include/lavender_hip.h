@@ -169,6 +169,10 @@ typedef struct lav_attn_desc {
     int n_types;
     const void* comb;         /* bf16 (n_types, heads, 8 q-tiles, 8 k-tiles, 64 lanes, 16): keys x queries fragments */
     const void* combT;        /* same, queries x keys fragments (dK/dV pass) */
+    int causal_from;          /* sequence mode: 0 = plain key mask ("full", model.py:219); > 0 = the seq2seq mask of
+                                 LAVENDER_Base.get_attn_mask (model.py:208-218) with this many prefix (video / pre-text) keys:
+                                 prefix keys follow key_mask for every query, text keys are causal among the text queries
+                                 and invisible to the prefix queries */
 } lav_attn_desc;
 
 int lav_attention_fwd(void* stream, const lav_attn_desc* d, const void* qkv, void* out, float* lse);

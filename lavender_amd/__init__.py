@@ -12,6 +12,7 @@ from .model import EncVideo, EncTxt, LAVENDER_Base  # noqa: F401
 from .pretrain_mlm import LAVENDER_Pretrain_MLM, Agent_Pretrain_MLM, masking  # noqa: F401
 from .pretrain_task_specific import LAVENDER_Pretrain, Agent_Pretrain  # noqa: F401
 from .retrieval_mlm import LAVENDER_Retrieval_MLM, Agent_Retrieval_MLM, LAVENDER_RetrievalMlmEval  # noqa: F401
+from .captioning import LAVENDER_Captioning  # noqa: F401
 from .agent import Agent_Base, WarmupLinearLR, CrossEntropyIgnore  # noqa: F401
 
 VIOLET_Base = LAVENDER_Base

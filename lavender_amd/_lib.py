@@ -50,7 +50,7 @@ class AttnDesc(C.Structure):
                 ("wd", i32), ("wh", i32), ("ww", i32), ("sd", i32), ("sh", i32), ("sw", i32), ("cfg_wh", i32),
                 ("cfg_ww", i32), ("cfg_wd", i32), ("bias_table", vp), ("n_seq", i32), ("L", i32), ("key_mask", vp),
                 ("dropout_p", f32), ("seed", u32), ("scale", f32), ("tok_table", vp), ("win_type", vp), ("type_region", vp),
-                ("n_types", i32), ("comb", vp), ("combT", vp)]
+                ("n_types", i32), ("comb", vp), ("combT", vp), ("causal_from", i32)]
 
 
 P = C.POINTER

@@ -16,7 +16,10 @@
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int HD, int MODE, int KT, int KL>
+// CAUSAL (sequence mode): the seq2seq mask of LAVENDER_Base.get_attn_mask (model.py:208-218): keys below causal_from (the video
+// / pre-text prefix) follow the key mask for EVERY query; keys at or above it (the text) are visible only to text queries at
+// or after them (lower-triangular block); prefix queries see no text key.
+template <int HD, int MODE, int KT, int KL, bool CAUSAL = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                  // KL x HD bf16, K-type swizzle
@@ -128,7 +131,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                             const float ads[4] = {ad.x, ad.y, ad.z, ad.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float v = fmaf(s[kt][r4 * 4 + e], sc, ads[e]);
+                                float v = fmaf(s[kt][r4 * 4 + e], sc, ads[e]);
+                                if (CAUSAL) {
+                                    const int kk = kc0 + k0 + 8 * r4 + 4 * hi + e;
+                                    if (kk >= a.d.causal_from && (q < a.d.causal_from || kk > q)) v = -INFINITY;
+                                }
                                 s[kt][r4 * 4 + e] = v;
                                 mx = fmaxf(mx, v);
                             }
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 //   S^T = K Q^T ; P^T = exp(S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - delta) ; dQ^T = K^T dS^T * scale
 // delta[q] = sum_d dO[q,d] O[q,d] is computed here and stored (fp32, lse layout, second half of the lse buffer).
 // ------------------------------------------------------------------------------------------------
-template <int HD, int MODE, int KL>
+template <int HD, int MODE, int KL, bool CAUSAL = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a, float* delta_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                  // K-type (A operand of S^T)
@@ -349,8 +356,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a, float* del
                             const float m0 = (h & 0xffffu) >= a.thresh16 ? inv : 0.f;
                             const float m1 = (h >> 16) >= a.thresh16 ? inv : 0.f;
                             const int r = r4 * 4 + 2 * e2;
-                            const float p0 = fast_exp2(fmaf(s[r], sc, ads[2 * e2]) - lse_q);
-                            const float p1 = fast_exp2(fmaf(s[r + 1], sc, ads[2 * e2 + 1]) - lse_q);
+                            float p0 = fast_exp2(fmaf(s[r], sc, ads[2 * e2]) - lse_q);
+                            float p1 = fast_exp2(fmaf(s[r + 1], sc, ads[2 * e2 + 1]) - lse_q);
+                            if (CAUSAL) {
+                                const int kk = kc0 + k0 + 8 * r4 + 4 * hi + 2 * e2;
+                                if (kk >= a.d.causal_from && (q < a.d.causal_from || kk > q)) p0 = 0.f;
+                                if (kk + 1 >= a.d.causal_from && (q < a.d.causal_from || kk + 1 > q)) p1 = 0.f;
+                            }
                             ds[r] = p0 * (dp[r] * m0 - dl);
                             ds[r + 1] = p1 * (dp[r + 1] * m1 - dl);
                         }
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a, float* del
 //   S = Q K^T (queries x keys) ; P = exp(S - lse[q]) ; dP = dO V^T ; dS = P o (dP - delta[q])
 //   dV^T = dO^T P~   (P~ = dropout(P)) ;  dK^T = Q^T dS * scale
 // ------------------------------------------------------------------------------------------------
-template <int HD, int MODE, int QL>
+template <int HD, int MODE, int QL, bool CAUSAL = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a, const float* delta_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;                                  // K-type: A operand of S
@@ -543,7 +555,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a, const 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int r = r4 * 4 + e;
-                            const float p = fast_exp2(fmaf(s[r], sc, k_add) - ls[e]);
+                            float p = fast_exp2(fmaf(s[r], sc, k_add) - ls[e]);
+                            if (CAUSAL) {
+                                const int qq = qc0 + qb + e;
+                                if (key >= a.d.causal_from && (qq < a.d.causal_from || key > qq)) p = 0.f;
+                            }
                             const uint32_t h = lav_hash32(a.d.seed, rb + (uint32_t)e * nh);   // p = 0: thresh16 = 0 keeps everything
                             const float m = ((h >> sh) & 0xffffu) >= a.thresh16 ? inv : 0.f;
                             pd[r] = p * m;
@@ -646,6 +662,7 @@ int attn_setup(const lav_attn_desc* d, AttnArgs& a, int& problems) {
     } else {
         LAV_REQUIRE(d->head_dim == 64, "attention(sequence): head_dim must be 64 (got %d)", d->head_dim);
         LAV_REQUIRE(d->n_seq > 0 && d->L > 0, "attention(sequence): bad shape");
+        LAV_REQUIRE(d->causal_from >= 0 && d->causal_from <= d->L, "attention(sequence): causal_from %d outside [0, L]", d->causal_from);
         a.N = d->L;
         problems = d->n_seq;
     }
@@ -698,8 +715,13 @@ extern "C" int lav_attention_fwd(void* stream, const lav_attn_desc* d, const voi
         hipLaunchKernelGGL((attn_fwd_kernel<32, 0, 8, WIN_KL>), grid, block, lds, s, a);
     } else {
         size_t lds = (size_t)SEQ_KL_FWD * 64 * 2 * 2 + SEQ_KL_FWD * 4;
-        set_lds(attn_fwd_kernel<64, 1, 3, SEQ_KL_FWD>, lds);
-        hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 3, SEQ_KL_FWD>), grid, block, lds, s, a);
+        if (d->causal_from > 0) {
+            set_lds(attn_fwd_kernel<64, 1, 3, SEQ_KL_FWD, true>, lds);
+            hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 3, SEQ_KL_FWD, true>), grid, block, lds, s, a);
+        } else {
+            set_lds(attn_fwd_kernel<64, 1, 3, SEQ_KL_FWD>, lds);
+            hipLaunchKernelGGL((attn_fwd_kernel<64, 1, 3, SEQ_KL_FWD>), grid, block, lds, s, a);
+        }
     }
     return lav_check_launch("lav_attention_fwd");
 }
@@ -732,14 +754,25 @@ extern "C" int lav_attention_bwd(void* stream, const lav_attn_desc* d, const voi
         a.R = one ? qgroups : 1;
         dim3 grid(problems * d->heads, one ? 1 : qgroups), block(256);
         size_t lds1 = (size_t)SEQ_KL * 64 * 2 * 3 + SEQ_KL * 4;
-        set_lds(attn_bwd_dq_kernel<64, 1, SEQ_KL>, lds1);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 1, SEQ_KL>), grid, block, lds1, s, a, delta);
+        const bool causal = d->causal_from > 0;
+        if (causal) {
+            set_lds(attn_bwd_dq_kernel<64, 1, SEQ_KL, true>, lds1);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 1, SEQ_KL, true>), grid, block, lds1, s, a, delta);
+        } else {
+            set_lds(attn_bwd_dq_kernel<64, 1, SEQ_KL>, lds1);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 1, SEQ_KL>), grid, block, lds1, s, a, delta);
+        }
         const bool one2 = a.N <= SEQ_QL;
         a.R = one2 ? qgroups : 1;
         dim3 grid2(problems * d->heads, one2 ? 1 : qgroups);
         size_t lds2 = (size_t)SEQ_QL * 64 * 2 * 4 + SEQ_QL * 12;
-        set_lds(attn_bwd_dkv_kernel<64, 1, SEQ_QL>, lds2);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 1, SEQ_QL>), grid2, block, lds2, s, a, (const float*)delta);
+        if (causal) {
+            set_lds(attn_bwd_dkv_kernel<64, 1, SEQ_QL, true>, lds2);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 1, SEQ_QL, true>), grid2, block, lds2, s, a, (const float*)delta);
+        } else {
+            set_lds(attn_bwd_dkv_kernel<64, 1, SEQ_QL>, lds2);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 1, SEQ_QL>), grid2, block, lds2, s, a, (const float*)delta);
+        }
     }
     return lav_check_launch("lav_attention_bwd");
 }

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void v_attn_kernel(VAttn a) {
                     if (kreg[q] != kreg[k]) s += -100.0f;
                 } else {
                     s = kreg[k] ? -INFINITY : dot;
+                    if (d.causal_from > 0 && k >= d.causal_from && (q < d.causal_from || k > q)) s = -INFINITY;   // seq2seq mask
                 }
             }
             sc[k] = s;

@@ -383,7 +383,7 @@ class BertLayerFn(torch.autograd.Function):
     """One post-LN BertLayer of the fusion encoder (HF BertLayer as called from model.py:242)."""
 
     @staticmethod
-    def forward(ctx, anchor, x, x32, layer, key_mask, n, L, p_hidden, p_attn, want32):
+    def forward(ctx, anchor, x, x32, layer, key_mask, n, L, p_hidden, p_attn, want32, causal_from=0):
         """x: (R, H) bf16 layer input (GEMM operand); x32: its fp32 copy for the residual add, or None (first layer:
         the embeddings are bf16); returns (y bf16, y32 fp32 or None when want32 is false)."""
         R, Hd = x.shape
@@ -397,7 +397,7 @@ class BertLayerFn(torch.autograd.Function):
         keep = _keep(ctx)
         qkv = K.gemm(0, x, wqkv16, R, 3 * Hd, Hd, bias=bqkv)
         s_att, s1, s2 = K.next_seed(), K.next_seed(), K.next_seed()
-        att = K.Attn(1, heads, Hd // heads, n_seq=n, L=L, key_mask=key_mask, dropout_p=p_attn, seed=s_att)
+        att = K.Attn(1, heads, Hd // heads, n_seq=n, L=L, key_mask=key_mask, dropout_p=p_attn, seed=s_att, causal_from=int(causal_from))
         lse = torch.empty(att.lse_elems(), dtype=torch.float32, device=x.device) if keep else None
         cx = torch.empty((R, Hd), dtype=bf16, device=x.device)
         att.fwd(qkv, cx, lse)
@@ -452,7 +452,7 @@ class BertLayerFn(torch.autograd.Function):
         att.bwd(qkv, cx, d_cx, lse, dqkv, None)
         dw_gemm(dqkv, x, 3 * Hd, Hd, R, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, R), rowsum_a=gbqkv)
         dx = K.gemm(0, dqkv, W16T(att_m.query.weight), R, Hd, 3 * Hd, residual=d_pre1)
-        return None, dx, None, None, None, None, None, None, None, None
+        return None, dx, None, None, None, None, None, None, None, None, None
 
 
 class MLMHeadFn(torch.autograd.Function):

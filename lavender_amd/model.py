@@ -153,12 +153,24 @@ class LAVENDER_Base(nn.Module):
         return feat_img, mask_img, feat_txt, mask
 
     def get_attn_mask(self, mask_img, mask_txt, attn_mask_type="full", mask_pretxt=None):
-        if attn_mask_type != "full" or mask_pretxt is not None:
-            raise NotImplementedError("seq2seq / pre-text masks (model.py:204-218) belong to the captioning path")
+        """model.py:194-221.  "full": (B, L) concatenation of the 0/1 masks.  "seq2seq" (captioning): the (B, L, L) mask of
+        model.py:208-218 -- every query sees the video keys (by mask_img), text queries additionally see the text keys up to
+        themselves, video queries see no text key.  The attention kernels take it as (key mask, number of prefix keys)."""
+        if mask_pretxt is not None:
+            raise NotImplementedError("pre-text (prompt / task-token) masks (model.py:200-203) are outside the built paths")
+        if attn_mask_type == "seq2seq":
+            _B, _Lv = mask_img.shape
+            _Lt = mask_txt.shape[1]
+            _L = _Lv + _Lt
+            mask = torch.zeros((_B, _L, _L), dtype=torch.long, device=mask_img.device)
+            mask[:, :, :_Lv] = mask_img[:, None, :]
+            mask[:, _Lv:, _Lv:] = torch.tril(torch.ones((_Lt, _Lt), dtype=torch.long, device=mask_img.device))
+            return mask
         return torch.cat([mask_img, mask_txt], dim=1)
 
-    def _encode(self, feat, mask):
-        """feat (n, L, H) bf16, mask (n, L) 0/1 -> last_hidden_state (n, L, H)."""
+    def _encode(self, feat, mask, causal_from=0):
+        """feat (n, L, H) bf16, mask (n, L) 0/1 key mask -> last_hidden_state (n, L, H).  causal_from > 0: seq2seq mask with that
+        many prefix (video) keys (lav_attn_desc.causal_from)."""
         arena = self.arena()
         arena.sync_half_if_stale()                            # e.g. load_ckpt followed directly by a 'cross' call on cached features
         n, L, Hd = feat.shape
@@ -170,7 +182,7 @@ class LAVENDER_Base(nn.Module):
         pa = self.config.attention_probs_dropout_prob if self.training else 0.0
         x32, last = None, len(self.trsfr.layer) - 1
         for i, lyr in enumerate(self.trsfr.layer):
-            x, x32 = E.BertLayerFn.apply(arena.anchor, x, x32, lyr, km, n, L, ph, pa, i < last)
+            x, x32 = E.BertLayerFn.apply(arena.anchor, x, x32, lyr, km, n, L, ph, pa, i < last, int(causal_from))
         return x.view(n, L, Hd)
 
     def go_cross(self, feat_img, mask_img, feat_txt, mask_txt, attn_mask_type="full", feat_pretxt=None, mask_pretxt=None):
@@ -179,6 +191,10 @@ class LAVENDER_Base(nn.Module):
         n = feat_img.shape[0]
         ident = np.arange(n)
         feat = E.PairSeqFn.apply(feat_img, feat_txt, ident, ident)
+        if attn_mask_type == "seq2seq":
+            # (B, L, L) mask of get_attn_mask in kernel form: video keys by mask_img, text keys all valid but causal
+            key_mask = torch.cat([mask_img, torch.ones_like(mask_txt)], dim=1)
+            return self._encode(feat, key_mask, causal_from=mask_img.shape[1]), None
         mask = self.get_attn_mask(mask_img, mask_txt, attn_mask_type=attn_mask_type)
         assert feat.shape[1] == mask.shape[1], f"mask and feat must have the same length, got {feat.shape[1]} vs. {mask.shape[1]}"
         return self._encode(feat, mask), None
@@ -195,7 +211,7 @@ class LAVENDER_Base(nn.Module):
     def prepro_txt_inputs(self, txt, mask_txt, feat_txt, task_name=None, prompt=None):
         """model.py:292-307 with enable_task_token / enable_prompt off (the shipped pretrain config): identity."""
         if getattr(self.args, "enable_task_token", False) or (prompt is not None and getattr(self.args, "enable_prompt", False)):
-            raise NotImplementedError("task tokens / prompts are outside the pretrain hot path")
+            raise NotImplementedError("task tokens / prompts are outside the built paths")
         return txt, mask_txt, feat_txt
 
     # ---- checkpoint contract (model.py:352-429) ----------------------------------------------------

@@ -124,7 +124,7 @@ def pair_sequences(f_img, f_txt, vi, ti):
     return out.view(n, L, Hd)
 
 
-def encode(model, feat, mask):
+def encode(model, feat, mask, causal_from=0):
     """The 12 post-LN BertLayers of go_cross (model.py:239-243) on fp32 rows."""
     n, L, Hd = feat.shape
     km = mask.to(torch.int32).contiguous()
@@ -135,7 +135,7 @@ def encode(model, feat, mask):
         _, _, wqkv = arena.fused_view(att_m.query.weight, 3 * Hd)
         _, _, bqkv = arena.fused_view(att_m.query.bias, 3 * Hd)
         qkv = linear(x, None, weight=wqkv, bias=bqkv)
-        att = K.Attn(1, lyr.num_heads, Hd // lyr.num_heads, n_seq=n, L=L, key_mask=km, dropout_p=0.0, seed=0)
+        att = K.Attn(1, lyr.num_heads, Hd // lyr.num_heads, n_seq=n, L=L, key_mask=km, dropout_p=0.0, seed=0, causal_from=int(causal_from))
         cx = _buf(n * L, Hd, x.device)
         K.v_attention(att, qkv, cx)
         x = layernorm(linear(cx, ao.dense, residual=x), ao.LayerNorm, ao.LayerNorm.eps)

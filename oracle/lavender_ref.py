@@ -259,8 +259,23 @@ def enc_txt(P, txt, drop=None):
 
 
 def extended_mask(mask, dtype=torch.float32):
-    """get_extended_attention_mask as used at model.py:239: (B,L) 0/1 -> additive (B,1,1,L)."""
-    return (1.0 - mask[:, None, None, :].to(dtype)) * torch.finfo(dtype).min
+    """get_extended_attention_mask as used at model.py:239: (B,L) 0/1 -> additive (B,1,1,L); a (B,L,L) mask (seq2seq)
+    -> (B,1,L,L)."""
+    m = mask[:, None, None, :] if mask.dim() == 2 else mask[:, None, :, :]
+    return (1.0 - m.to(dtype)) * torch.finfo(dtype).min
+
+
+def attn_mask(m_img, m_txt, attn_mask_type="full"):
+    """LAVENDER_Base.get_attn_mask, model.py:194-221 (mask_pretxt=None)."""
+    if attn_mask_type == "seq2seq":
+        B, Lv = m_img.shape
+        Lt = m_txt.shape[1]
+        L = Lv + Lt
+        mask = torch.zeros((B, L, L), dtype=torch.long)
+        mask[:, :, :Lv] = m_img[:, None, :]
+        mask[:, Lv:, Lv:] = torch.tril(torch.ones((B, Lt, Lt), dtype=torch.long))
+        return mask
+    return torch.cat([m_img, m_txt], 1)
 
 
 def bert_layer(P, pre, x, add_mask, heads, drop=None):
@@ -298,10 +313,10 @@ def n_fusion_layers(P):
     return n
 
 
-def go_cross(P, f_img, m_img, f_txt, m_txt, heads, drops=None):
-    """LAVENDER_Base.go_cross, model.py:223-243 ("full" mask).  drops: per-layer dropout multipliers (see bert_layer)."""
+def go_cross(P, f_img, m_img, f_txt, m_txt, heads, drops=None, attn_mask_type="full"):
+    """LAVENDER_Base.go_cross, model.py:223-243.  drops: per-layer dropout multipliers (see bert_layer)."""
     x = torch.cat([f_img, f_txt], 1)
-    add = extended_mask(torch.cat([m_img, m_txt], 1))
+    add = extended_mask(attn_mask(m_img, m_txt, attn_mask_type))
     for i in range(n_fusion_layers(P)):
         x = bert_layer(P, f"trsfr.layer.{i}", x, add, heads, None if drops is None else drops[i])
     return x
@@ -378,6 +393,17 @@ def pretrain_loss(out):
     l_mtm = F.cross_entropy(out["out_mtm"].reshape(-1, V), out["ans_mtm"].reshape(-1), ignore_index=-1)
     l_vtm = F.cross_entropy(out["out_vtm"].reshape(-1, V), out["ans_vtm"].reshape(-1), ignore_index=-1)
     return l_mtm, l_vtm
+
+
+def captioning_encode_forward(P, batch, size, heads):
+    """LAVENDER_Captioning.encode_forward, model_for_captioning.py:54-95 (prompt / task token off): go_feat, go_cross with the
+    seq2seq mask, MLM head on the text positions."""
+    img, txt, mask = batch["img"], batch["txt"], batch["mask"]
+    f_img, m_img = enc_video(P, img, size)
+    f_txt = enc_txt(P, txt)
+    Lv = f_img.shape[1]
+    out = go_cross(P, f_img, m_img, f_txt, mask, heads, attn_mask_type=batch.get("attn_mask_type", "seq2seq"))
+    return dict(out=mlm_head(P, out[:, Lv:]), ans=batch.get("ans_mtm"))
 
 
 def score_head(P, x):

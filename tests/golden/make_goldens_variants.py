@@ -147,6 +147,42 @@ def run_retrieval_eval(ref):
     assert d1 < 2e-5 and d2 < 2e-5
 
 
+def run_captioning(ref):
+    """LAVENDER_Captioning.encode_forward (model_for_captioning.py:54-95) under the seq2seq attention mask of
+    LAVENDER_Base.get_attn_mask (model.py:208-218): logits on the text positions, MLM loss, gradients."""
+    CAP = importlib.import_module("model_for_captioning")
+    B, swin, bert = 2, "micro", "micro"
+    m, keys = build(ref, CAP.LAVENDER_Captioning, swin, bert, B)
+    vocab, heads = BERT_CFGS[bert]["vocab_size"], BERT_CFGS[bert]["num_attention_heads"]
+    batch = make_batch(B, vocab=vocab, seed=6)
+    torch.manual_seed(88)
+    batch["txt"], ans = R.masking(batch["txt"])
+    m.eval()
+    mask3 = m.get_attn_mask(torch.ones(B, 250, dtype=torch.long), batch["mask"], attn_mask_type="seq2seq")
+    out = m({"img": batch["img"], "txt": batch["txt"].clone(), "mask": batch["mask"], "ans_mtm": ans.clone(), "attn_mask_type": "seq2seq"})
+    lf = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    ls = lf(out["out"].flatten(0, 1), out["ans"].flatten())
+    m.zero_grad()
+    ls.backward()
+    gk, gv = grads_of(m)
+    named = {k.replace("trsfr.enc.", "trsfr."): p for k, p in m.named_parameters()}
+    V = out["out"].shape[-1]
+    cols = torch.randperm(V, generator=torch.Generator().manual_seed(5))[:256]
+    np.savez_compressed(
+        f"{HERE}/cap_micro_b2.npz", txt=batch["txt"].numpy(), ans=ans.numpy(), mask_rows=mask3[:, [0, 249, 250, 260, 281]].numpy().astype(np.int8),
+        out_cols=out["out"][:, :, cols].detach().numpy().astype(np.float32), cols=cols.numpy(),
+        out_lse=torch.logsumexp(out["out"], -1).detach().numpy(), loss=np.array([ls.item()]), grad_norm_keys=gk, grad_norm_vals=gv,
+        **{"grad_sub::" + k: sub(named[k].grad, 2048) for k in ("trsfr.layer.0.attention.self.key.weight", "enc_img.emb_pos",
+                                                               "enc_txt.emb_txt.position_embeddings.weight")},
+        meta=np.array([swin, bert, str(B), "224", str(heads)]))
+    P = {k.replace("trsfr.enc.", "trsfr."): v.detach() for k, v in m.state_dict().items()}
+    o = R.captioning_encode_forward(P, dict(batch, ans_mtm=ans, attn_mask_type="seq2seq"), swin, heads)
+    d = (o["out"] - out["out"]).abs().max().item()
+    same_mask = bool((R.attn_mask(torch.ones(B, 250, dtype=torch.long), batch["mask"], "seq2seq") == mask3).all())
+    print(f"   captioning (seq2seq mask): oracle vs reference max|d| {d:.2e}; mask identical {same_mask}; loss {ls.item():.4f}")
+    assert d < 2e-5 and same_mask
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ref = MG.import_reference()
@@ -165,4 +201,6 @@ if __name__ == "__main__":
         run_retrieval(ref)
     if not only or "retrieval_eval" in only:
         run_retrieval_eval(ref)
+    if not only or "captioning" in only:
+        run_captioning(ref)
     print("variant goldens written to", HERE)

@@ -390,6 +390,36 @@ def test_sequence_attention_fwd_bwd(n, L, heads):
     close(dqkv, qr.grad, atol=4e-2, rtol=4e-2, what="seq dqkv")
 
 
+@pytest.mark.parametrize("n,L,Lv,heads", [(3, 282, 250, 2), (2, 757, 725, 1), (2, 70, 50, 1)])
+def test_sequence_attention_seq2seq_mask_fwd_bwd(n, L, Lv, heads):
+    """Causal-block mode (lav_attn_desc.causal_from = number of prefix keys; LAVENDER_Base.get_attn_mask "seq2seq",
+    model.py:208-218) against fp32 torch on the explicit (n, L, L) mask -- on random rows, where the mask moves the outputs by
+    O(1): forward, dQ pass and dK/dV pass."""
+    Hd = heads * 64
+    qkv = rb(n * L, 3 * Hd)
+    km = torch.ones(n, L, dtype=torch.int32)
+    km[0, Lv - 9:Lv - 2] = 0                                           # masked video keys (vt_mask), for every query
+    att = K().Attn(1, heads, 64, n_seq=n, L=L, key_mask=km.cuda(), dropout_p=0.0, seed=0, causal_from=Lv)
+    lse = torch.empty(att.lse_elems(), device="cuda")
+    out = torch.empty(n * L, Hd, dtype=bf16, device="cuda")
+    att.fwd(qkv, out, lse)
+    m3 = torch.zeros(n, L, L)
+    m3[:, :, :Lv] = km[:, None, :Lv].float()
+    m3[:, Lv:, Lv:] = torch.tril(torch.ones(L - Lv, L - Lv))
+    qr = qkv.float().cpu().requires_grad_(True)
+    q, k, v = [t.reshape(n, L, heads, 64).transpose(1, 2) for t in qr.split(Hd, -1)]
+    sc = q @ k.transpose(-1, -2) / 8.0 + (1.0 - m3[:, None]) * torch.finfo(torch.float32).min
+    ref = (sc.softmax(-1) @ v).transpose(1, 2).reshape(n * L, Hd)
+    close(out, ref, atol=2e-2, what="seq2seq fwd")
+    full = _seq_ref(qkv.float().cpu(), torch.ones(n, L, dtype=torch.int32), n, L, heads)
+    assert (full - ref).abs().max() > 0.08                             # the mask is not a no-op on this input (4x the tolerance)
+    dout = rb(n * L, Hd, seed=4)
+    ref.backward(dout.float().cpu())
+    dqkv = torch.empty_like(qkv)
+    att.bwd(qkv, out, dout, lse, dqkv, None)
+    close(dqkv, qr.grad, atol=4e-2, rtol=4e-2, what="seq2seq dqkv")
+
+
 def test_sequence_attention_dropout_statistics():
     n, L, heads, p = 4, 282, 2, 0.1
     Hd = heads * 64

@@ -395,3 +395,54 @@ def test_load_ckpt_refreshes_the_working_copies(tmp_path):
     lc, gc = run(c)
     assert torch.equal(lc, la)
     assert ((gc - ga).norm() / ga.norm()).item() < 1e-4       # atomics in the small-vector gradients: order-dependent rounding
+
+
+def test_captioning_seq2seq_matches_oracle_and_golden(golden_dir):
+    """LAVENDER_Captioning.encode_forward on the HIP path (causal-block mode of the fusion attention kernels, forward and both
+    backward passes) against the oracle and the reference golden: logits, loss, every gradient; plus the (B, L, L) mask tensor
+    of get_attn_mask bit-exact, and the fp32 validation kernels on the same mask."""
+    from oracle import lavender_ref as R
+    from tests.helpers import build_filled_model
+    from lavender_amd import LAVENDER_Captioning, validate
+    from lavender_amd.agent import CrossEntropyIgnore
+    g = np.load(os.path.join(golden_dir, "cap_micro_b2.npz"))
+    swin, bert, B = "micro", "micro", 2
+    bc = BERT_CFGS[bert]
+    P = R.filled_params(swin, hidden=bc["hidden"], layers=bc["layers"], ffn=bc["ffn"], vocab=bc["vocab"])
+    for v in P.values():
+        v.requires_grad_(True)
+    batch = make_batch(B, vocab=bc["vocab"], seed=6)
+    torch.manual_seed(88)
+    batch["txt"], ans = R.masking(batch["txt"])
+    ref = R.captioning_encode_forward(P, dict(batch, ans_mtm=ans), swin, bc["heads"])
+    lref = torch.nn.functional.cross_entropy(ref["out"].flatten(0, 1), ans.flatten(), ignore_index=-1)
+    lref.backward()
+    m = build_filled_model(swin, bert, B, cls=LAVENDER_Captioning).eval()
+    m3 = m.get_attn_mask(torch.ones(B, 250, dtype=torch.long), batch["mask"], attn_mask_type="seq2seq")
+    assert (m3[:, [0, 249, 250, 260, 281]].numpy() == g["mask_rows"]).all()
+    m.arena().zero_grad()
+    out = m({"img": batch["img"].cuda(), "txt": batch["txt"].cuda(), "mask": batch["mask"].cuda(), "ans_mtm": ans.cuda(),
+             "attn_mask_type": "seq2seq"})
+    a, b = out["out"].detach().float().cpu(), ref["out"].detach()
+    d = (a - b).abs()
+    print("captioning logits max", d.max().item(), "mean", d.mean().item())
+    assert d.max() < 1.5e-2 and d.mean() < 2.5e-3
+    cols = torch.from_numpy(g["cols"])
+    np.testing.assert_allclose(a[:, :, cols].numpy(), g["out_cols"], atol=1.5e-2)
+    ls = CrossEntropyIgnore()(out["out"].flatten(0, 1), out["ans"].flatten())
+    ls.backward()
+    torch.cuda.synchronize()
+    assert abs(ls.item() - g["loss"][0]) < 1e-2 and abs(ls.item() - lref.item()) < 1e-2
+    _grad_check(m, P, rel_tol=0.05)
+    # (with these small key-filled weights attention is nearly uniform, so the mask moves the logits by less than the bf16
+    # tolerance: the kernel-level test_sequence_attention_seq2seq_mask_fwd_bwd is the sharp check of the mask itself)
+    # fp32 validation kernels under the same mask
+    with torch.no_grad():
+        f_img = validate.enc_video(m.enc_img, batch["img"].cuda())
+        f_txt = validate.enc_txt(m.enc_txt, batch["txt"].cuda())
+        km = torch.cat([torch.ones(B, 250, dtype=torch.long), torch.ones_like(batch["mask"])], 1).cuda()
+        hid = validate.encode(m, validate.pair_sequences(f_img, f_txt, np.arange(B), np.arange(B)), km, causal_from=250)
+        lg = validate.mlm_head(m.fc_mtm, hid[:, 250:])
+    d32 = (lg.cpu() - b).abs().max().item()
+    print("fp32 validation mode, seq2seq: max|d|", d32)
+    assert d32 <= 1e-3

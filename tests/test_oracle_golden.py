@@ -261,3 +261,24 @@ def test_retrieval_eval_two_phase(golden_dir):
     np.testing.assert_allclose(sub(f_txt), g["f_txt_sub"], atol=1e-5)
     np.testing.assert_allclose(out[:, :, torch.from_numpy(g["cols"])].numpy(), g["out_cols"], atol=1e-5)
     np.testing.assert_allclose(torch.logsumexp(out, -1).numpy(), g["out_lse"], atol=1e-5)
+
+
+def test_captioning_seq2seq_variant(golden_dir):
+    """LAVENDER_Captioning.encode_forward under the seq2seq mask (model.py:208-218, model_for_captioning.py:54-95): the oracle
+    against the vectors captured from the real reference (logits, loss, gradient norms); the (B, L, L) mask rows bit-exact."""
+    g = _load(golden_dir, "cap_micro_b2")
+    P, bc = _variant_params("micro", "micro")
+    B = 2
+    batch = make_batch(B, vocab=bc["vocab"], seed=6)
+    torch.manual_seed(88)
+    batch["txt"], ans = R.masking(batch["txt"])
+    assert (batch["txt"].numpy() == g["txt"]).all() and (ans.numpy() == g["ans"]).all()
+    m3 = R.attn_mask(torch.ones(B, 250, dtype=torch.long), batch["mask"], "seq2seq")
+    assert (m3[:, [0, 249, 250, 260, 281]].numpy() == g["mask_rows"]).all()
+    out = R.captioning_encode_forward(P, dict(batch, ans_mtm=ans), "micro", bc["heads"])
+    cols = torch.from_numpy(g["cols"])
+    np.testing.assert_allclose(out["out"][:, :, cols].detach().numpy(), g["out_cols"], atol=1e-5)
+    ls = torch.nn.functional.cross_entropy(out["out"].flatten(0, 1), ans.flatten(), ignore_index=-1)
+    assert abs(ls.item() - g["loss"][0]) < 1e-5
+    ls.backward()
+    _check_grads(P, g)
