@@ -12,6 +12,7 @@
 // Wave w owns 32-row tile w of the 256-slot window (8 tiles).  Scores use the exp2 domain: the bias tables are
 // pre-multiplied by log2(e).
 #include "attn_common.h"
+#include <stdlib.h>
 
 #define LOG2E 1.4426950408889634f
 #define HD 32
@@ -610,8 +611,13 @@ int win_persistent_fwd(void* stream, const AttnArgs& a) {
     return lav_check_launch("lav_attention_fwd(window, persistent)");
 }
 
+// LAV_WIN_BWD_FUSED=1 selects the single-kernel backward of attention_win_bwd.hip (measured slower on every Swin-B stage:
+// 10.9 vs 8.9 ms per step); the default is the two-pass form below (dQ + bias gradient, then dK / dV)
+static const bool lav_win_bwd_fused = getenv("LAV_WIN_BWD_FUSED") ? atoi(getenv("LAV_WIN_BWD_FUSED")) != 0 : false;
+
 int win_persistent_bwd(void* stream, const AttnArgs& a, float* delta) {
     const int bs = pick_bsplit(a);
+    if (lav_win_bwd_fused) return win_fused_bwd(stream, a, bs);
     const size_t lds1 = 2 * 49152 + 2048 + (size_t)a.tbl_rows * 16;
     // with the bias-table gradient the resident dS sums need the 512-register budget of one wave per SIMD (the 8-wave
     // variant spills in its inner loop: 375 vs 309 us on the stage-2 shape); without it two waves per SIMD win (202 vs 230 us)

@@ -28,6 +28,7 @@ struct AttnArgs {
 int attn_setup(const lav_attn_desc* d, AttnArgs& a, int& problems);
 int win_persistent_fwd(void* stream, const AttnArgs& a);
 int win_persistent_bwd(void* stream, const AttnArgs& a, float* delta);
+int win_fused_bwd(void* stream, const AttnArgs& a, int bsplit);
 
 // fast window path: token rows from the precomputed per-window table instead of div/mod chains
 __device__ __forceinline__ int tok_row(const AttnArgs& a, int win, int i) {
