@@ -87,6 +87,28 @@ def _keep(ctx):
     return any(ctx.needs_input_grad)
 
 
+_PAD_MAPS = {}
+
+
+def pad_maps(device, B, grid, window):
+    """Row maps between a (B, D, H, W) token grid and the same grid zero-padded at the far edges up to multiples of `window`
+    (F.pad of video_swin.py:211-215 / :273-276 as two row gathers).  None when nothing is padded; else
+    ((Dp, Hp, Wp), padded row count, to_pad[int32: padded row -> real row or -1], to_real[int32: real row -> padded row])."""
+    D, H, W = grid
+    Dp, Hp, Wp = (-(-g // w) * w for g, w in zip(grid, window))
+    if (Dp, Hp, Wp) == (D, H, W):
+        return None
+    key = (str(device), B, D, H, W, Dp, Hp, Wp)
+    if key not in _PAD_MAPS:
+        real = np.arange(B * D * H * W, dtype=np.int32).reshape(B, D, H, W)
+        to_pad = np.full((B, Dp, Hp, Wp), -1, dtype=np.int32)
+        to_pad[:, :D, :H, :W] = real
+        to_real = np.arange(B * Dp * Hp * Wp, dtype=np.int32).reshape(B, Dp, Hp, Wp)[:, :D, :H, :W]
+        _PAD_MAPS[key] = ((Dp, Hp, Wp), B * Dp * Hp * Wp, torch.from_numpy(to_pad.reshape(-1)).to(device),
+                          torch.from_numpy(np.ascontiguousarray(to_real).reshape(-1)).to(device))
+    return _PAD_MAPS[key]
+
+
 # ---------------------------------------------------------------------------------------------------
 # Swin stages
 # ---------------------------------------------------------------------------------------------------
@@ -133,13 +155,24 @@ class SwinBlockFn(torch.autograd.Function):
         a, mlp = blk.attn, blk.mlp
         keep = _keep(ctx)
         y1, mean1, rstd1 = K.layernorm_fwd(x, M, C, blk.norm1.weight.data, blk.norm1.bias.data, 1e-5, want_stats=keep)
-        qkv = K.gemm(0, y1, W16(a.qkv.weight), M, 3 * C, C, bias=a.qkv.bias.data)
         win, sh, cfg = geo["window"], geo["shift"], geo["cfg_window"]
+        pad = pad_maps(x.device, B, (D, H, Wd), win)
+        if pad is not None:
+            # zero rows AFTER norm1 up to window multiples (video_swin.py:211-215): the qkv GEMM then gives the padded tokens
+            # q = k = v = bias, exactly what Linear(0) is in the reference; they attend and are attended to (no mask)
+            (D, H, Wd), Ma, to_pad, to_real = pad
+            y1 = K.gather_rows(y1, to_pad, Ma, C)
+        else:
+            Ma = M
+        qkv = K.gemm(0, y1, W16(a.qkv.weight), Ma, 3 * C, C, bias=a.qkv.bias.data)
         att = K.Attn(0, heads, C // heads, B=B, D=D, H=H, W=Wd, wd=win[0], wh=win[1], ww=win[2], sd=sh[0], sh=sh[1],
                      sw=sh[2], cfg_wd=cfg[0], cfg_wh=cfg[1], cfg_ww=cfg[2], bias_table=a.relative_position_bias_table.data)
         lse = torch.empty(att.lse_elems(), dtype=torch.float32, device=x.device) if keep else None
-        ao = torch.empty((M, C), dtype=bf16, device=x.device)
+        ao = torch.empty((Ma, C), dtype=bf16, device=x.device)
         att.fwd(qkv, ao, lse)
+        ao_p = ao
+        if pad is not None:
+            ao = K.gather_rows(ao_p, to_real, M, C)       # crop (video_swin.py:241-242), before proj: proj is row-wise
         x_mid = K.gemm(0, ao, W16(a.proj.weight), M, C, C, bias=a.proj.bias.data, row_scale=dp_attn, rows_per_group=rpg,
                        residual=x)
         y2, mean2, rstd2 = K.layernorm_fwd(x_mid, M, C, blk.norm2.weight.data, blk.norm2.bias.data, 1e-5, want_stats=keep)
@@ -153,20 +186,24 @@ class SwinBlockFn(torch.autograd.Function):
             ctx.arena = geo.get("arena")
             ctx.keep_attn = float(blk.keep_prob) if dp_attn is not None else 1.0
             ctx.has_dp = dp_attn is not None
+            ctx.pad = pad
             ctx.save_for_backward(x, y1, mean1, rstd1, qkv, ao, lse, x_mid, y2, mean2, rstd2, h_pre, h,
                                   dp_attn if dp_attn is not None else x.new_empty(0),
-                                  dp_mlp if dp_mlp is not None else x.new_empty(0))
+                                  dp_mlp if dp_mlp is not None else x.new_empty(0),
+                                  ao_p if pad is not None else x.new_empty(0))
         return out
 
     @staticmethod
     def backward(ctx, dy):
         blk, att, rpg = ctx.blk, ctx.att, ctx.rpg
         a, mlp = blk.attn, blk.mlp
-        x, y1, mean1, rstd1, qkv, ao, lse, x_mid, y2, mean2, rstd2, h_pre, h, dp_attn, dp_mlp = ctx.saved_tensors
+        x, y1, mean1, rstd1, qkv, ao, lse, x_mid, y2, mean2, rstd2, h_pre, h, dp_attn, dp_mlp, ao_p = ctx.saved_tensors
         if not ctx.has_dp:
             dp_attn = dp_mlp = None
         alpha = 1.0 / ctx.keep_attn
         M, C = x.shape
+        pad = ctx.pad
+        Ma = M if pad is None else pad[1]
         dy = dy.contiguous()
         # --- MLP branch: out = x_mid + s * fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------
         dw_gemm(dy, h, C, 4 * C, M, out=G(mlp.fc2.weight), accumulate=True, k_keep=dp_mlp, k_rows_per_group=rpg,
@@ -183,10 +220,16 @@ class SwinBlockFn(torch.autograd.Function):
                alpha=alpha if dp_attn is not None else 1.0, splits=K.splits_for(C, C, M, dp_attn is not None), rowsum_a=G(a.proj.bias))
         d_ao = K.gemm(0, d_mid, W16T(a.proj.weight), M, C, C, row_scale=dp_attn, rows_per_group=rpg)
         dqkv = torch.empty_like(qkv)
+        if pad is not None:
+            # padded geometry: zero output-gradient rows for the padded tokens; their dK / dV (they ARE attended to) reach the
+            # qkv bias through the row sum over all Ma rows, the weight sees nothing from them (their y1 rows are zero)
+            d_ao, ao = K.gather_rows(d_ao, pad[2], Ma, C), ao_p
         att.bwd(qkv, ao, d_ao, lse, dqkv, G(a.relative_position_bias_table))
-        dw_gemm(dqkv, y1, 3 * C, C, M, out=G(a.qkv.weight), accumulate=True, splits=K.splits_for(3 * C, C, M),
+        dw_gemm(dqkv, y1, 3 * C, C, Ma, out=G(a.qkv.weight), accumulate=True, splits=K.splits_for(3 * C, C, Ma),
                rowsum_a=G(a.qkv.bias))
-        d_y1 = K.gemm(0, dqkv, W16T(a.qkv.weight), M, C, 3 * C)
+        d_y1 = K.gemm(0, dqkv, W16T(a.qkv.weight), Ma, C, 3 * C)
+        if pad is not None:
+            d_y1 = K.gather_rows(d_y1, pad[3], M, C)
         dx = K.layernorm_bwd(d_y1, x, M, C, blk.norm1.weight.data, mean1, rstd1, G(blk.norm1.weight), G(blk.norm1.bias),
                              add_in=d_mid)
         if ctx.notify and ctx.arena is not None:
@@ -200,12 +243,17 @@ class PatchMergeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, x, mod, BT, H, W):
         M, C = x.shape
-        assert H % 2 == 0 and W % 2 == 0, "PatchMerging with odd H/W (pad branch video_swin.py:274-276) is not supported"
+        pad = None
+        if H % 2 or W % 2:
+            # odd H / W: one zero row / column at the far edge before the 2x2 gather (video_swin.py:273-276)
+            pad = pad_maps(x.device, BT, (1, H, W), (1, 2, 2))
+            (_, H, W), M, to_pad, _ = pad
+            x = K.gather_rows(x, to_pad, M, C)
         rows = M // 4
         y, mean, rstd = K.layernorm_fwd(x, rows, 4 * C, mod.norm.weight.data, mod.norm.bias.data, 1e-5, gather=(H, W, C),
                                         want_stats=_keep(ctx))
         out = K.gemm(0, y, W16(mod.reduction.weight), rows, 2 * C, 4 * C)
-        ctx.mod, ctx.geo = mod, (H, W, C)
+        ctx.mod, ctx.geo, ctx.pad = mod, (H, W, C), pad
         ctx.save_for_backward(x, y, mean, rstd)
         return out
 
@@ -220,6 +268,8 @@ class PatchMergeFn(torch.autograd.Function):
         d_y = K.gemm(0, dout, W16T(mod.reduction.weight), rows, 4 * C, 2 * C)
         dx = K.layernorm_bwd(d_y, x, rows, 4 * C, mod.norm.weight.data, mean, rstd, G(mod.norm.weight), G(mod.norm.bias),
                              gather=(H, W, C))
+        if ctx.pad is not None:
+            dx = K.gather_rows(dx, ctx.pad[3], len(ctx.pad[3]), C)
         return None, dx, None, None, None, None
 
 

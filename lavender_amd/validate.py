@@ -78,7 +78,12 @@ def swin_tokens(swin, img, frame_major=True, taps=None):
         if taps is not None:
             taps[f"stage{s}"] = x
         if layer.downsample is not None:
-            assert Hc % 2 == 0 and Wc % 2 == 0, "PatchMerging with odd H/W (video_swin.py:273-276) is not supported"
+            if Hc % 2 or Wc % 2:                          # zero row / column at the far edge (video_swin.py:273-276)
+                from .engine import pad_maps
+                (_, Hc, Wc), Mp, to_pad, _ = pad_maps(dev, B * D, (1, Hc, Wc), (1, 2, 2))
+                xp = _buf(Mp, C, dev)
+                K.v_gather_rows(x, to_pad, Mp, C, xp)
+                x = xp
             y = layernorm(x, layer.downsample.norm, 1e-5, gather=(Hc, Wc, C), rows=x.shape[0] // 4)
             x = linear(y, layer.downsample.reduction)
             Hc, Wc = Hc // 2, Wc // 2

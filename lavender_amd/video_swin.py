@@ -232,7 +232,7 @@ class SwinTransformer3D(nn.Module):
                 taps[f"stage{s}"] = x
             if layer.downsample is not None:
                 x = E.PatchMergeFn.apply(anchor, x, layer.downsample, B * D, Hc, Wc)
-                Hc, Wc = Hc // 2, Wc // 2
+                Hc, Wc = (Hc + 1) // 2, (Wc + 1) // 2
         x = E.LayerNormFn.apply(anchor, x, self.norm, 1e-5)
         return x, (B, D, Hc, Wc)
 

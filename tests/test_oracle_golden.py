@@ -282,3 +282,23 @@ def test_captioning_seq2seq_variant(golden_dir):
     assert abs(ls.item() - g["loss"][0]) < 1e-5
     ls.backward()
     _check_grads(P, g)
+
+
+def test_swin_pad_branch_gradients(golden_dir):
+    """Oracle vs the reference on padded token grids, forward AND backward (fixture: tests/golden/make_goldens_pad.py):
+    5x64^2 / 4x96^2 (window padding) and 2x40^2 (odd H / W in PatchMerging, video_swin.py:273-276)."""
+    g = _load(golden_dir, "swin_pad_grads")
+    for B, T, S in ((2, 5, 64), (2, 2, 40), (1, 4, 96)):
+        tag = f"B{B}_T{T}_S{S}"
+        P = {k: v.requires_grad_(True) for k, v in R.filled_params("micro", hidden=128, layers=0, ffn=512, vocab=64).items()}
+        x = torch.randn(B, 3, T, S, S, generator=torch.Generator().manual_seed(3))
+        y = R.swin_forward(P, "enc_img.swin", x, "micro")
+        assert tuple(y.shape) == tuple(g[f"{tag}_shape"])
+        np.testing.assert_allclose(sub(y, 2048), g[f"{tag}_sub"], atol=2e-5)
+        w = torch.randn(y.shape, generator=torch.Generator().manual_seed(11))
+        (y * w).sum().backward()
+        for k, n in zip(g[f"{tag}_grad_keys"].tolist(), g[f"{tag}_grad_norms"].tolist()):
+            assert abs(P["enc_img.swin." + k].grad.double().norm().item() - n) <= 1e-4 * n + 2e-6, k
+        for k in g.files:
+            if k.startswith(f"{tag}_grad_sub::"):
+                np.testing.assert_allclose(sub(P["enc_img.swin." + k.split("::")[1]].grad, 1024), g[k], atol=2e-5, rtol=1e-3)
