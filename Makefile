@@ -2,20 +2,20 @@
 HIPCC ?= hipcc
 ARCH  ?= gfx950
 CSRC  := lavender_amd/csrc
-OBJS  := $(CSRC)/gemm.o $(CSRC)/layernorm.o $(CSRC)/attention.o $(CSRC)/attention_win.o $(CSRC)/attention_win_bwd.o $(CSRC)/embed.o $(CSRC)/loss_optim.o $(CSRC)/validate.o $(CSRC)/runtime.o
+OBJS  := $(CSRC)/gemm.o $(CSRC)/layernorm.o $(CSRC)/attention.o $(CSRC)/attention_win.o $(CSRC)/attention_win_bwd.o $(CSRC)/embed.o $(CSRC)/loss_optim.o $(CSRC)/validate.o $(CSRC)/pipeline.o $(CSRC)/runtime.o
 LIB   := lavender_amd/liblavender_hip.so
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value -munsafe-fp-atomics
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/attn_common.h include/lavender_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/attn_common.h include/lavender_hip.h include/lavender_pipeline.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(CSRC)/runtime.o: $(CSRC)/runtime.cpp $(CSRC)/common.h include/lavender_hip.h
 	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -lpthread -o $@
 
 probe: $(LIB) tools/gemm_probe.cpp
 	$(HIPCC) $(FLAGS) tools/gemm_probe.cpp -o tools/gemm_probe -Llavender_amd -llavender_hip -Wl,-rpath,'$$ORIGIN/../lavender_amd'

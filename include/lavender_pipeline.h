@@ -1,0 +1,70 @@
+/* lavender_pipeline.h -- C ABI of the MI355X input pipeline of the LAVENDER pretrain path.
+ *
+ * The reference reads one TSV line per sample (id + base64 JPEG frames), decodes every frame on a DataLoader worker with
+ * cv2 / PIL (libjpeg), resizes / crops / normalises it with torchvision on the CPU and ships fp32 frames over PCIe.
+ * Here the host only does the serial part (base64 + Huffman entropy decode, multi-threaded C++), the quantised DCT
+ * coefficients go over PCIe (int16, ~0.4x the bytes of the fp32 frames) and the GPU does the rest: dequantise + inverse
+ * DCT, chroma upsampling, YCbCr -> RGB, antialiased bilinear resize, crop, /255 and mean / std normalisation, written
+ * straight into the (B, T, 3, S, S) fp32 batch tensor.  Every stage restates the published integer algorithm of the library
+ * the reference calls (libjpeg "islow" IDCT, "fancy" h2v1 / h2v2 upsampling and fixed-point colour conversion; Pillow's
+ * 8-bit two-pass resample with 22-bit coefficients), so the frames are BIT-IDENTICAL to the reference's CPU path.
+ *
+ * Reference interfaces replaced (paths relative to the reference root):
+ *   lav_tsv_*                dataset.py:40-46 (read_tsv / seek_img_tsv), main_pretrain_task_specific.py:50-78
+ *   lav_jpeg_peek            PIL.Image.size of dataset.py:177-186 (str2img)
+ *   lav_decoder_decode       dataset.py:177-186 (str2img: base64 -> cv2.imdecode -> RGB) followed by one of
+ *                            dataset.py:107-118 pad_resize, :120-130 img_center_crop, :164-175 img_rand_crop
+ *                            (torchvision Pad / Resize / CenterCrop / RandomCrop / ToTensor / Normalize) per frame and
+ *                            T.cat / T.stack of dataset.py:252, main_pretrain_task_specific.py:112-114
+ *
+ * Conventions: C linkage, POD arguments, 0 or a negative LAV_E_* code, message through lav_last_error() of lavender_hip.h.
+ */
+#ifndef LAVENDER_PIPELINE_H
+#define LAVENDER_PIPELINE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* --- TSV + lineidx (memory-mapped, zero-copy field pointers) ------------------------------------------------------------ */
+/* lineidx_path: the reference's ".lineidx" text file (one byte offset per line), or NULL to index every line start. */
+void* lav_tsv_open(const char* tsv_path, const char* lineidx_path);
+long lav_tsv_rows(void* tsv);
+long lav_tsv_row_offset(void* tsv, long row);            /* byte offset of row `row` (what the reference seeks to) */
+/* Splits the line starting at byte offset `pos` at tabs and strips surrounding whitespace (dataset.py:44-46).  Returns the
+ * number of fields found (at most max_fields are reported), or a negative error code.  Pointers stay valid until close. */
+int lav_tsv_fields(void* tsv, long pos, int max_fields, const char** field, long* field_len);
+void lav_tsv_close(void* tsv);
+
+/* --- JPEG header ---------------------------------------------------------------------------------------------------------- */
+/* Width / height of a base64-encoded baseline JPEG (only the header is decoded). */
+int lav_jpeg_peek(const char* b64, long b64_len, int* width, int* height);
+
+/* --- batch decoder --------------------------------------------------------------------------------------------------------- */
+typedef struct lav_frame_xform {
+    int pad_left, pad_top;       /* zero padding added on BOTH sides of that axis before the resize (pad_resize, dataset.py:110) */
+    int resize_w, resize_h;      /* size after the antialiased bilinear resize; equal to the padded size = no resize */
+    int crop_x, crop_y;          /* top-left corner of the crop window in the resized frame */
+    long out_index;              /* frame slot in the output tensor: out + out_index * 3 * out_h * out_w floats */
+} lav_frame_xform;
+
+/* n_threads host threads for base64 + entropy decoding.  Buffers grow on demand. */
+void* lav_decoder_create(int n_threads);
+void lav_decoder_destroy(void* dec);
+/* Decodes n_frames base64 JPEGs and writes normalised fp32 frames (3, out_h, out_w) into the DEVICE tensor `out`:
+ *   out[c][y][x] = (rgb8 / 255 - mean[c]) / std[c],  rgb8 = crop(resize(pad(decode(jpeg)))).
+ * The host stage runs inside the call (on n_threads threads); the device stage is only enqueued on `stream`.  The call
+ * may be issued from a prefetch thread while another stream trains; two pinned staging sets are cycled, each guarded by an
+ * event, so the call blocks only if the copy of the batch before the previous one is still in flight. */
+int lav_decoder_decode(void* dec, void* stream, int n_frames, const char* const* b64, const long* b64_len,
+                       const lav_frame_xform* xf, int out_h, int out_w, const float* mean3, const float* std3, float* out);
+/* Debug / test taps of the last decoded batch (device -> host copies, synchronous): the full-resolution RGB frame
+ * (h * w * 3 bytes, after padding) of frame i. */
+int lav_decoder_read_rgb(void* dec, int frame, uint8_t* rgb, long capacity, int* w, int* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -94,14 +94,35 @@ _SIGS = {
     "lav_v_text_embed_f32": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp]),
     "lav_v_gather_rows_f32": (i32, [vp, i32, i32, vp, i64, vp, vp, i64]),
 }
+
+
+class FrameXform(C.Structure):               # struct lav_frame_xform (include/lavender_pipeline.h)
+    _fields_ = [("pad_left", i32), ("pad_top", i32), ("resize_w", i32), ("resize_h", i32), ("crop_x", i32), ("crop_y", i32),
+                ("out_index", i64)]
+
+
+# input pipeline (include/lavender_pipeline.h)
+_PIPE_SIGS = {
+    "lav_tsv_open": (vp, [C.c_char_p, C.c_char_p]),
+    "lav_tsv_rows": (i64, [vp]),
+    "lav_tsv_row_offset": (i64, [vp, i64]),
+    "lav_tsv_fields": (i32, [vp, i64, i32, P(vp), P(i64)]),
+    "lav_tsv_close": (None, [vp]),
+    "lav_jpeg_peek": (i32, [vp, i64, P(i32), P(i32)]),
+    "lav_decoder_create": (vp, [i32]),
+    "lav_decoder_destroy": (None, [vp]),
+    "lav_decoder_decode": (i32, [vp, vp, i32, P(vp), P(i64), P(FrameXform), i32, i32, P(f32), P(f32), vp]),
+    "lav_decoder_read_rgb": (i32, [vp, i32, vp, i64, P(i32), P(i32)]),
+}
 class MatDesc(C.Structure):                  # struct lav_mat_desc
     _fields_ = [("src_off", C.c_long), ("dst_off", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("ld_dst", C.c_int),
                 ("tile0", C.c_int)]
 
 
 EXPORTS = tuple(_SIGS)
+PIPELINE_EXPORTS = tuple(_PIPE_SIGS)
 
-for _name, (_res, _args) in _SIGS.items():
+for _name, (_res, _args) in {**_SIGS, **_PIPE_SIGS}.items():
     try:
         _f = getattr(lib, _name)
     except AttributeError as e:  # pragma: no cover

@@ -1,0 +1,398 @@
+"""Input pipeline of the pretrain path: TSV(+lineidx) rows of base64 JPEG frames -> normalised
+fp32 frames in HBM.  Mirrors the reference's dataset.py / main_pretrain_task_specific.py surface for this path:
+
+    Dataset_Base       dataset.py:18-276      token ids, sampling / temporal_sample, transform choice, str2txt, *_mask_tok2txt
+    Dataset_Pretrain   main_pretrain_task_specific.py:15-122   TSV row -> (frames, txt, mask), collate_batch
+    get_dl             dataset.py:279-292     Random / Sequential / Distributed sampler semantics, batches of size_batch
+
+What differs is WHERE the pixels are made: `__getitem__` only plans a sample -- it picks the frames, the transform and the crop
+offsets, drawing from `random` / `torch` in exactly the reference's order -- and the batch is decoded in one call of the C-ABI
+decoder (include/lavender_pipeline.h): base64 + Huffman decode on host threads, then IDCT, chroma upsampling, colour
+conversion, antialiased resize, crop and normalisation as HIP kernels writing the (B, T, 3, S, S) tensor in HBM.  A prefetch
+thread with its own stream keeps one batch ahead of the training step.  The frames are bit-identical to the reference's
+(cv2 / PIL decode + torchvision transforms); tests/test_gpu_pipeline.py holds that against fixtures made with Pillow.
+
+`vid_rand_crop` / `vid_center_crop` (the clip transforms of visbackbone/video_transform.py, not used by the pretrain configs)
+are not implemented and raise.
+"""
+import ctypes as C
+import math
+import queue
+import random
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+MEAN = (0.485, 0.456, 0.406)          # dataset.py:114-116
+STD = (0.229, 0.224, 0.225)
+
+
+class TsvFile:
+    """Memory-mapped TSV with the reference's .lineidx (dataset.py:40-46; _tools/extract_tsv.py:20-27 writes the format)."""
+
+    def __init__(self, tsv_path, lineidx_path=None):
+        self._h = L.lib.lav_tsv_open(str(tsv_path).encode(), str(lineidx_path).encode() if lineidx_path else None)
+        if not self._h:
+            L.check(-1, "lav_tsv_open")
+        self.path = str(tsv_path)
+
+    def __len__(self):
+        return int(L.lib.lav_tsv_rows(self._h))
+
+    def offset(self, row):
+        off = L.lib.lav_tsv_row_offset(self._h, int(row))
+        if off < 0:
+            L.check(-1, "lav_tsv_row_offset")
+        return int(off)
+
+    def fields(self, pos, max_fields=64):
+        """[(address, length)] of the tab-separated, whitespace-stripped fields of the line at byte offset `pos`."""
+        ptr = (L.vp * max_fields)()
+        ln = (L.i64 * max_fields)()
+        n = L.lib.lav_tsv_fields(self._h, int(pos), max_fields, ptr, ln)
+        if n < 0:
+            L.check(n, "lav_tsv_fields")
+        if n > max_fields:
+            return self.fields(pos, n)
+        return [(int(ptr[i] or 0), int(ln[i])) for i in range(n)]
+
+    def seek(self, pos):
+        """dataset.py:44-46 seek_img_tsv: the fields as strings."""
+        return [C.string_at(p, n).decode() if n else "" for p, n in self.fields(pos)]
+
+    def close(self):
+        if self._h:
+            L.lib.lav_tsv_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def _ref(buf):
+    """(address, length, keep-alive) of a base64 JPEG given as a TSV field reference, bytes or str."""
+    if isinstance(buf, tuple):
+        return buf[0], buf[1], None
+    if isinstance(buf, str):
+        buf = buf.encode()
+    keep = C.create_string_buffer(buf, len(buf))
+    return C.addressof(keep), len(buf), keep
+
+
+def jpeg_size(buf):
+    """(width, height) as PIL.Image.size would report after dataset.py:177-186 str2img."""
+    p, n, _keep = _ref(buf)
+    w, h = L.i32(), L.i32()
+    L.check(L.lib.lav_jpeg_peek(p, n, C.byref(w), C.byref(h)), "lav_jpeg_peek")
+    return w.value, h.value
+
+
+def resized_size(w, h, size):
+    """torchvision Resize(int) on a (w, h) image: the shorter side becomes `size`, the other int(size * long / short)."""
+    short, long_ = (w, h) if w <= h else (h, w)
+    new_short, new_long = size, int(size * long_ / short)
+    return (new_short, new_long) if w <= h else (new_long, new_short)
+
+
+class FramePlan:
+    """One frame of a sample: the JPEG and the geometric transform the decoder applies to it."""
+    __slots__ = ("buf", "pad_left", "pad_top", "resize_w", "resize_h", "crop_x", "crop_y")
+
+    def __init__(self, buf, pad_left, pad_top, resize_w, resize_h, crop_x, crop_y):
+        self.buf, self.pad_left, self.pad_top = buf, pad_left, pad_top
+        self.resize_w, self.resize_h, self.crop_x, self.crop_y = resize_w, resize_h, crop_x, crop_y
+
+
+class FrameDecoder:
+    """Batch JPEG decoder + transforms on the GPU (lav_decoder_* of include/lavender_pipeline.h)."""
+
+    def __init__(self, n_threads=4):
+        self._h = L.lib.lav_decoder_create(int(n_threads))
+        if not self._h:
+            L.check(-1, "lav_decoder_create")
+        self._mean = (L.f32 * 3)(*MEAN)
+        self._std = (L.f32 * 3)(*STD)
+
+    def decode(self, plans, size, out=None, slots=None, stream=None):
+        """plans: FramePlan list -> (len(plans), 3, size, size) fp32 on the GPU (or written into `out` at frame slots `slots`).
+        Enqueued on `stream` (default: torch's current stream); the host part (base64, Huffman) runs inside the call."""
+        n = len(plans)
+        if not torch.cuda.is_available():
+            raise RuntimeError("lavender_amd runs on the MI355X only: the frame decoder has no CPU path")
+        if out is None:
+            out = torch.empty((n, 3, size, size), dtype=torch.float32, device="cuda")
+        ptr, ln, xf, keep = (L.vp * n)(), (L.i64 * n)(), (L.FrameXform * n)(), []
+        for i, p in enumerate(plans):
+            a, k, ka = _ref(p.buf)
+            keep.append(ka)
+            ptr[i], ln[i] = a, k
+            xf[i] = L.FrameXform(p.pad_left, p.pad_top, p.resize_w, p.resize_h, p.crop_x, p.crop_y, i if slots is None else int(slots[i]))
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        L.check(L.lib.lav_decoder_decode(self._h, st, n, ptr, ln, xf, size, size, self._mean, self._std, out.data_ptr()), "lav_decoder_decode")
+        return out
+
+    def last_rgb(self, i):
+        """Full-resolution RGB (H, W, 3) uint8 of frame i of the last batch (test tap)."""
+        cap = 1 << 26
+        buf = (C.c_uint8 * cap)()
+        w, h = L.i32(), L.i32()
+        L.check(L.lib.lav_decoder_read_rgb(self._h, int(i), buf, cap, C.byref(w), C.byref(h)), "lav_decoder_read_rgb")
+        return np.frombuffer(buf, dtype=np.uint8, count=3 * w.value * h.value).reshape(h.value, w.value, 3).copy()
+
+    def close(self):
+        if self._h:
+            L.lib.lav_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Dataset_Base:
+    """dataset.py:18-276 for the pretrain path."""
+
+    def __init__(self, args, split="train", size_frame=4, tokzr=None):
+        self.args, self.size_frame, self.split = args, size_frame, split
+        if tokzr is None:
+            raise ValueError("pass the tokenizer object (no network / model hub access in this build)")
+        self.tokzr = tokzr
+        (self.cls_token_id, self.sep_token_id, self.pad_token_id, self.mask_token_id, self.unk_token_id) = tokzr.convert_tokens_to_ids(
+            [tokzr.cls_token, tokzr.sep_token, tokzr.pad_token, tokzr.mask_token, tokzr.unk_token])
+        self.true_token_id = tokzr.convert_tokens_to_ids(["true"])[0]
+        self.false_token_id = tokzr.convert_tokens_to_ids(["false"])[0]
+        self._py_rng, self._torch_gen = random, None      # the process-global generators, as in a reference worker process
+
+    def set_rng(self, py_rng, torch_gen):
+        """Private generators for the sampling / crop draws (the reference's DataLoader workers are separate processes with
+        their own seeds; a prefetch THREAD must not interleave its draws with the trainer's masking / dropout draws)."""
+        self._py_rng, self._torch_gen = py_rng, torch_gen
+
+    # ---- text (dataset.py:83-105, 258-276) ----------------------------------------------------------------------------
+    def append_mask_tok2txt(self, txt, mask):
+        one = torch.LongTensor([1])
+        return torch.cat([txt, self.mask_token_id * one], -1), torch.cat([mask, one], -1)
+
+    def prepend_mask_tok2txt(self, txt, mask):
+        one = torch.LongTensor([1])
+        return torch.cat([self.mask_token_id * one, txt], -1), torch.cat([one, mask], -1)
+
+    def replace_cls_w_mask(self, txt, mask):
+        one = torch.LongTensor([1])
+        return torch.cat([self.mask_token_id * one, txt[1:]], -1), torch.cat([one, mask[1:]], -1)
+
+    def str2txt(self, s):
+        txt = self.tokzr.encode(s, padding="max_length", max_length=self.args.size_txt, truncation=True)
+        mask = torch.LongTensor([1 if w != self.pad_token_id else 0 for w in txt])
+        txt = torch.LongTensor(txt)
+        assert len(txt[txt == self.sep_token_id]) == 1, f"{txt}"
+        return txt, mask
+
+    # ---- frames (dataset.py:188-256) -----------------------------------------------------------------------------------
+    def sampling(self, start, end, n):
+        if n == 1:
+            return [int(round((start + end) / 2.))]
+        if n < 1:
+            raise Exception("behaviour not defined for n<2")
+        step = (end - start) / float(n - 1)
+        return [int(round(start + x * step)) for x in range(n)]
+
+    def temporal_sample(self, list_of_b, random_sample=False):
+        max_size_frame = len(list_of_b)
+        if max_size_frame == 1 or self.size_frame == max_size_frame:
+            return list_of_b
+        size_frame = min(self.size_frame, max_size_frame)
+        size_clips = int(math.ceil(max_size_frame / size_frame))
+        if random_sample:
+            sampled_start = self._py_rng.choice(range(size_clips))
+            sampled_end = min(sampled_start + (size_frame - 1) * size_clips, max_size_frame - 1)
+        else:
+            sampled_start, sampled_end = 0, max_size_frame - 1
+        return [list_of_b[i] for i in self.sampling(sampled_start, sampled_end, size_frame)]
+
+    def _plan_one(self, buf, transform):
+        S = int(self.args.size_img)
+        w, h = jpeg_size(buf)
+        if transform == "pad_resize":                     # dataset.py:107-118: Pad to a square, Resize([S, S])
+            pl, pt = (0, (w - h) // 2) if w > h else ((h - w) // 2, 0)
+            return FramePlan(buf, pl, pt, S, S, 0, 0)
+        rw, rh = resized_size(w, h, S)                    # Resize(S): dataset.py:121,166
+        if transform == "img_center_crop":                # CenterCrop: int(round((h - S) / 2.0)), Python rounding
+            return FramePlan(buf, 0, 0, rw, rh, int(round((rw - S) / 2.0)), int(round((rh - S) / 2.0)))
+        if transform == "img_rand_crop":                  # RandomCrop.get_params: torch.randint for the row, then the column
+            assert self.split == "train"
+            if rw == S and rh == S:
+                return FramePlan(buf, 0, 0, rw, rh, 0, 0)
+            i = torch.randint(0, rh - S + 1, size=(1,), generator=self._torch_gen).item()
+            j = torch.randint(0, rw - S + 1, size=(1,), generator=self._torch_gen).item()
+            return FramePlan(buf, 0, 0, rw, rh, j, i)
+        raise NotImplementedError(f"img_transform {transform!r}: the clip transforms of visbackbone/video_transform.py "
+                                  "(vid_rand_crop / vid_center_crop) are not part of this build")
+
+    def get_img_or_video(self, list_of_b):
+        """dataset.py:218-256, as a plan: the same frames, transforms and crop offsets (same RNG draws in the same order);
+        the pixels are produced by FrameDecoder.decode at batch time."""
+        bufs = self.temporal_sample(list_of_b, random_sample=(self.split == "train"))
+        plans = []
+        for b in bufs:
+            if self.split == "train":
+                t = self._py_rng.choice(self.args.img_transform)
+            elif self.args.img_transform == ["vid_rand_crop"]:
+                t = "vid_center_crop"
+            elif self.args.img_transform == ["pad_resize"]:
+                t = "pad_resize"
+            else:
+                t = "img_center_crop"
+            plans.append(self._plan_one(b, t))
+        return plans
+
+
+class Dataset_Pretrain(Dataset_Base):
+    """main_pretrain_task_specific.py:15-122 with explicit file paths (the reference derives them from dataset names)."""
+
+    def __init__(self, args, txt, tsv_path, lineidx_path, split="train", dataset="webvid2.5m", tokzr=None):
+        super().__init__(args, split=split, size_frame=args.size_frame, tokzr=tokzr)
+        if dataset in ["cc3m", "coco", "vg", "cc12m"]:
+            self.size_frame = 1
+        self.dataset = dataset
+        self.txt = txt[self.split] if isinstance(txt, dict) and self.split in txt else txt
+        self.tsv = TsvFile(tsv_path, lineidx_path)
+        self.lineidx = [self.tsv.offset(i) for i in range(len(self.tsv))]
+
+    def __len__(self):
+        return len(self.lineidx)
+
+    def __getitem__(self, idx):
+        item = self.tsv.fields(self.lineidx[idx])
+        vid = C.string_at(item[0][0], item[0][1]).decode()
+        bufs = item[2:] if self.dataset in ["webvid10m", "webvid10m_filtered"] and self.split == "train" else item[1:]
+        raw_txt = self.txt[vid][0] if vid in self.txt else ""
+        try:
+            plans = self.get_img_or_video(bufs)
+        except L.LavenderHipError as e:                   # main_pretrain_task_specific.py:98-106: zeros for unreadable frames
+            print(f"Failed to load image binaries for video {vid} for dataset {self.dataset}, split {self.split}, {e}")
+            plans = None
+        txt, mask = self.str2txt(raw_txt)
+        return plans, txt, mask
+
+
+class _Sampler:
+    """dataset.py:279-287: DistributedSampler(shuffle=train) / RandomSampler / SequentialSampler index order."""
+
+    def __init__(self, n, train, distributed, rank=0, world=1, seed=0):
+        self.n, self.train, self.distributed, self.rank, self.world, self.seed, self.epoch = n, train, distributed, rank, world, seed, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def indices(self):
+        if self.distributed:
+            if self.train:
+                g = torch.Generator()
+                g.manual_seed(self.seed + self.epoch)
+                idx = torch.randperm(self.n, generator=g).tolist()
+            else:
+                idx = list(range(self.n))
+            total = -(-self.n // self.world) * self.world
+            pad = total - len(idx)
+            if pad:
+                idx += (idx * math.ceil(pad / len(idx)))[:pad]
+            return idx[self.rank:total:self.world]
+        if self.train:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            g = torch.Generator()
+            g.manual_seed(seed)
+            return torch.randperm(self.n, generator=g).tolist()
+        return list(range(self.n))
+
+
+class PretrainLoader:
+    """get_dl (dataset.py:279-292) for Dataset_Pretrain: batches {"img": (B, T, 3, S, S) fp32, "txt", "mask"} on the GPU.
+    One batch is decoded ahead on a side stream by a prefetch thread (n_workers = host decode threads)."""
+
+    def __init__(self, ds, args, rank=0, world=1, prefetch=True):
+        self.ds, self.args = ds, args
+        self.sampler = _Sampler(len(ds), ds.split == "train", bool(getattr(args, "distributed", False)), rank, world)
+        self.decoder = FrameDecoder(max(1, int(getattr(args, "n_workers", 4))))
+        self.prefetch = prefetch
+        self._stream = None
+
+    def __len__(self):
+        return -(-len(self.sampler.indices() if self.sampler.distributed else range(len(self.ds))) // int(self.args.size_batch))
+
+    def _collate(self, items, stream):
+        S, T = int(self.args.size_img), max(len(p) for p, _, _ in items if p is not None) if any(p for p, _, _ in items) else self.ds.size_frame
+        B = len(items)
+        img = torch.empty((B, T, 3, S, S), dtype=torch.float32, device="cuda")
+        plans, slots = [], []
+        for b, (p, _, _) in enumerate(items):
+            if p is None or len(p) != T:
+                if p is not None:
+                    raise ValueError(f"sample {b} has {len(p)} frames, the batch {T} (T.stack of the reference fails as well)")
+                with torch.cuda.stream(stream):
+                    img[b].zero_()
+                continue
+            plans += p
+            slots += [b * T + t for t in range(T)]
+        if plans:
+            self.decoder.decode(plans, S, out=img, slots=slots, stream=stream)
+        txt = torch.stack([t for _, t, _ in items]).pin_memory()
+        mask = torch.stack([m for _, _, m in items]).pin_memory()
+        with torch.cuda.stream(stream):
+            batch = {"img": img, "txt": txt.cuda(non_blocking=True), "mask": mask.cuda(non_blocking=True)}
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return batch, ev
+
+    def _batches(self):
+        idx = self.sampler.indices()
+        bs = int(self.args.size_batch)
+        for i in range(0, len(idx), bs):
+            yield [self.ds[j] for j in idx[i:i + bs]]
+
+    def __iter__(self):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        if not self.prefetch:
+            for items in self._batches():
+                batch, ev = self._collate(items, self._stream)
+                torch.cuda.current_stream().wait_event(ev)
+                yield batch
+            return
+        q = queue.Queue(maxsize=2)
+        dev = torch.cuda.current_device()
+        if self.ds._torch_gen is None:                     # worker-style private seeds, drawn once from the global generator
+            base = int(torch.empty((), dtype=torch.int64).random_().item())
+            g = torch.Generator()
+            g.manual_seed(base)
+            self.ds.set_rng(random.Random(base), g)
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                for items in self._batches():
+                    q.put(self._collate(items, self._stream))
+                q.put(None)
+            except BaseException as e:                     # surfaced in the consumer
+                q.put(e)
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        while True:
+            got = q.get()
+            if got is None:
+                break
+            if isinstance(got, BaseException):
+                raise got
+            batch, ev = got
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for t in batch.values():
+                t.record_stream(cur)
+            yield batch
+        th.join()
+
+
+def get_dl(ds, args, rank=0, world=1):
+    return PretrainLoader(ds, args, rank=rank, world=world)

@@ -1,0 +1,141 @@
+"""CPU restatement of the reference's input pipeline for the pretrain path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product path
+(lavender_amd/data.py + lavender_amd/csrc/pipeline.hip) never does and has no CPU fallback.
+
+What is restated, and against what it is pinned:
+  * dataset.py:40-46, main_pretrain_task_specific.py:75-85   TSV seek + split                       -> read_row
+  * dataset.py:177-186  str2img: base64 -> cv2.imdecode / PIL.Image.open -> RGB                      -> str2img.  cv2 is absent from
+    this image; the function takes the reference's own `except` branch (PIL).  Both go through libjpeg(-turbo) with default
+    settings (islow IDCT, fancy upsampling), whose output is bit-identical across builds by design.
+  * dataset.py:107-118,120-130,164-175  pad_resize / img_center_crop / img_rand_crop                 -> same names here.
+    torchvision (v0.11+ semantics: Resize on a PIL image is PIL.Image.resize(BILINEAR), Pad fills 0, CenterCrop rounds with
+    Python round(), RandomCrop draws torch.randint for the row then the column, ToTensor = uint8 -> fp32 / 255, Normalize =
+    (x - mean) / std in fp32) is NOT installed here, so these few lines are restated from torchvision's published source and
+    executed with Pillow + torch on the CPU: the pixel arithmetic is Pillow's and torch's own.
+  * dataset.py:188-216  sampling / temporal_sample                                                   -> same names here.
+Parity pin: tests/golden/pipeline_frames.npz is written by tests/golden/make_goldens_pipeline.py from these functions running
+on Pillow in the build container (the reference's dataset.py itself imports torchvision and cv2 and cannot be imported).
+"""
+import base64
+import io
+import math
+import random
+
+import numpy as np
+import torch
+from PIL import Image
+
+MEAN = [0.485, 0.456, 0.406]
+STD = [0.229, 0.224, 0.225]
+
+
+def read_row(tsv_path, pos):
+    """dataset.py:44-46: seek, readline, split at tabs, strip."""
+    with open(tsv_path, "r") as f:
+        f.seek(pos)
+        return [s.strip() for s in f.readline().split("\t")]
+
+
+def str2img(b):
+    """dataset.py:177-186 (the PIL branch)."""
+    return Image.open(io.BytesIO(base64.b64decode(b))).convert("RGB")
+
+
+def _to_tensor_normalize(img):
+    """torchvision ToTensor + Normalize (dataset.py:113-116)."""
+    t = torch.from_numpy(np.array(img, np.uint8, copy=True)).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    mean = torch.as_tensor(MEAN, dtype=torch.float32).view(-1, 1, 1)
+    std = torch.as_tensor(STD, dtype=torch.float32).view(-1, 1, 1)
+    return t.sub_(mean).div_(std)
+
+
+def _resize_short(img, size):
+    """torchvision Resize(int): shorter side -> size, keep the aspect with int() truncation; unchanged if already there."""
+    w, h = img.size
+    short, long_ = (w, h) if w <= h else (h, w)
+    new_short, new_long = size, int(size * long_ / short)
+    nw, nh = (new_short, new_long) if w <= h else (new_long, new_short)
+    if (w, h) == (nw, nh):
+        return img
+    return img.resize((nw, nh), Image.BILINEAR)
+
+
+def pad_resize(img, size_img):
+    """dataset.py:107-118."""
+    w, h = img.size
+    pl, pt = (0, (w - h) // 2) if w > h else ((h - w) // 2, 0)
+    padded = Image.new("RGB", (w + 2 * pl, h + 2 * pt), 0)
+    padded.paste(img, (pl, pt))
+    if padded.size != (size_img, size_img):
+        padded = padded.resize((size_img, size_img), Image.BILINEAR)
+    return _to_tensor_normalize(padded)
+
+
+def img_center_crop(img, size_img):
+    """dataset.py:120-130."""
+    img = _resize_short(img, size_img)
+    w, h = img.size
+    top, left = int(round((h - size_img) / 2.0)), int(round((w - size_img) / 2.0))
+    return _to_tensor_normalize(img.crop((left, top, left + size_img, top + size_img)))
+
+
+def img_rand_crop(img, size_img, generator=None):
+    """dataset.py:164-175; RandomCrop.get_params draws the row offset, then the column offset."""
+    img = _resize_short(img, size_img)
+    w, h = img.size
+    if (w, h) == (size_img, size_img):
+        i = j = 0
+    else:
+        i = torch.randint(0, h - size_img + 1, size=(1,), generator=generator).item()
+        j = torch.randint(0, w - size_img + 1, size=(1,), generator=generator).item()
+    return _to_tensor_normalize(img.crop((j, i, j + size_img, i + size_img)))
+
+
+def sampling(start, end, n):
+    """dataset.py:188-194."""
+    if n == 1:
+        return [int(round((start + end) / 2.))]
+    if n < 1:
+        raise Exception("behaviour not defined for n<2")
+    step = (end - start) / float(n - 1)
+    return [int(round(start + x * step)) for x in range(n)]
+
+
+def temporal_sample(list_of_b, size_frame_cfg, random_sample=False, rng=random):
+    """dataset.py:196-216."""
+    max_size_frame = len(list_of_b)
+    if max_size_frame == 1 or size_frame_cfg == max_size_frame:
+        return list_of_b
+    size_frame = min(size_frame_cfg, max_size_frame)
+    size_clips = int(math.ceil(max_size_frame / size_frame))
+    if random_sample:
+        sampled_start = rng.choice(range(size_clips))
+        sampled_end = min(sampled_start + (size_frame - 1) * size_clips, max_size_frame - 1)
+    else:
+        sampled_start, sampled_end = 0, max_size_frame - 1
+    return [list_of_b[i] for i in sampling(sampled_start, sampled_end, size_frame)]
+
+
+def get_img_or_video(list_of_b, size_frame, size_img, img_transform, split="train", rng=random, generator=None):
+    """dataset.py:218-256 for the per-image transforms: (T, 3, S, S) fp32."""
+    bufs = temporal_sample(list_of_b, size_frame, random_sample=(split == "train"), rng=rng)
+    out = []
+    for b in bufs:
+        img = str2img(b)
+        if split == "train":
+            t = rng.choice(img_transform)
+        elif img_transform == ["pad_resize"]:
+            t = "pad_resize"
+        else:
+            t = "img_center_crop"
+        if t == "pad_resize":
+            x = pad_resize(img, size_img)
+        elif t == "img_center_crop":
+            x = img_center_crop(img, size_img)
+        elif t == "img_rand_crop":
+            x = img_rand_crop(img, size_img, generator)
+        else:
+            raise NotImplementedError(t)
+        out.append(x.unsqueeze(0))
+    return torch.cat(out, 0)

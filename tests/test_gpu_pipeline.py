@@ -1,0 +1,152 @@
+"""Input pipeline on the GPU (include/lavender_pipeline.h, lavender_amd/data.py) against the Pillow / torch CPU restatement of
+the reference's dataset.py (oracle/pipeline_ref.py) and the committed fixtures (tests/golden/pipeline_frames.npz,
+msrvtt_2rows.tsv: two rows of the reference's own sample TSV).  Byte / integer work: the bar is bit-exact; the final fp32 frames
+(three IEEE operations per value) must be equal as well."""
+import base64
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class WordTok:
+    """Whitespace tokenizer stub with the encode() signature dataset.py:270-272 uses."""
+    cls_token = "[CLS]"; sep_token = "[SEP]"; pad_token = "[PAD]"; mask_token = "[MASK]"; unk_token = "[UNK]"
+    ids = {"[PAD]": 0, "[UNK]": 100, "[CLS]": 101, "[SEP]": 102, "[MASK]": 103, "true": 2995, "false": 6270}
+
+    def convert_tokens_to_ids(self, toks):
+        return [self.ids[t] for t in toks]
+
+    def encode(self, s, padding=None, max_length=None, truncation=None):
+        ids = [101] + [1000 + (zlib.crc32(w.encode()) % 20000) for w in s.split()][:max_length - 2] + [102]
+        return ids + [0] * (max_length - len(ids))
+
+
+def sub(a, n=4096, seed=7):
+    flat = np.asarray(a).reshape(-1)
+    idx = np.random.RandomState(seed + flat.size % 9973).permutation(flat.size)[:n]
+    return flat[idx]
+
+
+def _args(**kw):
+    from lavender_amd.args import EasyDict
+    a = EasyDict(size_img=224, size_frame=4, size_txt=32, img_transform=["img_rand_crop"], size_batch=2, n_workers=4, distributed=False)
+    a.update(kw)
+    return a
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "pipeline_frames.npz"))
+
+
+def test_synthetic_jpegs_decode_and_transforms_bit_exact(gold):
+    """4:4:4 / 4:2:2 / 4:2:0 / grey, odd sizes, optimised Huffman tables, restart markers, 1x1: decoded frame and every
+    transform output equal the CPU path's."""
+    from lavender_amd import data as D
+    dec = D.FrameDecoder(2)
+    ds = D.Dataset_Base(_args(), split="train", tokzr=WordTok())
+    for name in gold["syn_names"].tolist():
+        b64 = base64.b64encode(gold[f"syn_{name}_jpg"].tobytes())
+        ref = gold[f"syn_{name}_rgb"]
+        if ref.ndim == 2:
+            ref = np.stack([ref] * 3, -1) if False else ref     # PIL .convert('RGB') already made 3 channels in the fixture
+        h, w = ref.shape[:2]
+        assert D.jpeg_size(b64) == (w, h)
+        for S in (8, 24):
+            ds.args.size_img = S
+            for t in ("pad_resize", "img_center_crop", "img_rand_crop"):
+                key = f"syn_{name}_{t}_{S}"
+                if key not in gold.files:
+                    continue
+                g = torch.Generator()
+                g.manual_seed(S)
+                ds.set_rng(random, g)
+                plan = ds._plan_one(b64, t)
+                out = dec.decode([plan], S)
+                torch.cuda.synchronize()
+                rgb = dec.last_rgb(0)[plan.pad_top:plan.pad_top + h, plan.pad_left:plan.pad_left + w]
+                assert np.array_equal(rgb, ref), f"{name}: decoded frame differs in {(rgb != ref).sum()} bytes (max {np.abs(rgb.astype(int) - ref).max()})"
+                got = out[0].cpu().numpy()
+                d = np.abs(got - gold[key]).max()
+                assert d == 0.0, f"{key}: max|d| {d}"
+
+
+def test_tsv_rows_match_reference_fixture(gold, golden_dir):
+    """Two rows of the reference's sample TSV: ids, frame sizes, decoded frames and the eval transforms at 224."""
+    from lavender_amd import data as D
+    tsv = D.TsvFile(os.path.join(golden_dir, "msrvtt_2rows.tsv"), os.path.join(golden_dir, "msrvtt_2rows.lineidx"))
+    assert len(tsv) == 2
+    dec = D.FrameDecoder(4)
+    ds = D.Dataset_Base(_args(), split="val", tokzr=WordTok())
+    for r in range(2):
+        f = tsv.fields(tsv.offset(r))
+        assert tsv.seek(tsv.offset(r))[0] == gold["tsv_ids"][r] and len(f) == 6
+        for t in ("pad_resize", "img_center_crop"):
+            plans = [ds._plan_one(b, t) for b in f[1:]]
+            out = dec.decode(plans, 224)
+            torch.cuda.synchronize()
+            for i in range(5):
+                if t == "img_center_crop":
+                    rgb = dec.last_rgb(i)
+                    assert np.array_equal(sub(rgb), gold[f"tsv_{r}_{i}_rgb_sub"])
+                    assert int(rgb.astype(np.int64).sum()) == int(gold[f"tsv_{r}_{i}_rgb_sum"][0]) and zlib.adler32(rgb.tobytes()) == int(gold[f"tsv_{r}_{i}_rgb_sum"][1])
+                x = out[i].cpu().numpy()
+                assert np.array_equal(sub(x), gold[f"tsv_{r}_{i}_{t}_sub"]), (r, i, t)
+                s = gold[f"tsv_{r}_{i}_{t}_sum"]
+                assert abs(x.astype(np.float64).sum() - s[0]) <= 1e-6 * s[1]
+
+
+def test_train_sample_plan_and_loader(gold, golden_dir):
+    """Dataset_Pretrain in train mode with the reference's draw order (temporal start, transform choice, crop row, crop column)
+    reproduces the seeded CPU sample; the prefetching loader yields the same batches as the synchronous one."""
+    from lavender_amd import data as D
+    from oracle import pipeline_ref as PR
+    tsvp, idxp = os.path.join(golden_dir, "msrvtt_2rows.tsv"), os.path.join(golden_dir, "msrvtt_2rows.lineidx")
+    txt = {"train": {k: [f"a video of {k} playing"] for k in gold["tsv_ids"].tolist()}}
+    args = _args(img_transform=["img_rand_crop", "pad_resize", "img_center_crop"])
+    ds = D.Dataset_Pretrain(args, txt, tsvp, idxp, split="train", dataset="msrvtt", tokzr=WordTok())
+    dec = D.FrameDecoder(4)
+    for r in range(2):
+        random.seed(5 + r)
+        g = torch.Generator()
+        g.manual_seed(5 + r)
+        ds.set_rng(random, g)
+        plans, t, m = ds[r]
+        assert len(plans) == 4 and t.shape == (32,) and int(m.sum()) == 7 and int(t[0]) == 101
+        x = dec.decode(plans, 224).cpu().numpy()
+        assert np.array_equal(sub(x), gold[f"tsv_train_{r}_sub"])
+        # and live against the CPU restatement on the same seeds
+        random.seed(5 + r)
+        g.manual_seed(5 + r)
+        ref = PR.get_img_or_video(PR.read_row(tsvp, ds.lineidx[r])[1:], 4, 224, args.img_transform, "train", random, g).numpy()
+        assert np.array_equal(x, ref)
+    # loader: synchronous vs prefetching, same private seeds
+    batches = []
+    for prefetch in (False, True):
+        g = torch.Generator()
+        g.manual_seed(11)
+        ds.set_rng(random.Random(11), g)
+        torch.manual_seed(3)                               # RandomSampler order
+        dl = D.PretrainLoader(ds, args, prefetch=prefetch)
+        got = [{k: v.clone() for k, v in b.items()} for b in dl]
+        assert len(got) == 1 and got[0]["img"].shape == (2, 4, 3, 224, 224) and got[0]["txt"].shape == (2, 32)
+        assert got[0]["img"].is_cuda and got[0]["txt"].is_cuda and got[0]["img"].dtype == torch.float32
+        batches.append(got[0])
+    for k in ("img", "txt", "mask"):
+        assert torch.equal(batches[0][k], batches[1][k]), k
+
+
+def test_decoder_rejects_bad_input():
+    from lavender_amd import data as D
+    from lavender_amd._lib import LavenderHipError
+    dec = D.FrameDecoder(1)
+    with pytest.raises(LavenderHipError):
+        dec.decode([D.FramePlan(base64.b64encode(b"not a jpeg at all"), 0, 0, 8, 8, 0, 0)], 8)
+    with pytest.raises(LavenderHipError):
+        D.jpeg_size(b"")

@@ -251,3 +251,44 @@ def test_hf_checkpoint_loader_renames_legacy_layernorm_keys_and_ties_the_decoder
     assert not res.missing_keys
     assert torch.equal(head.predictions.decoder.weight.data, sd["bert.embeddings.word_embeddings.weight"])
     assert torch.equal(head.predictions.transform.LayerNorm.weight.data, sd["cls.predictions.transform.LayerNorm.gamma"])
+
+
+def test_pipeline_library_exports_and_host_side(golden_dir):
+    """include/lavender_pipeline.h: every declared entry is exported; the host-only entries (TSV reader, JPEG header) work
+    without a GPU and agree with the CPU restatement of dataset.py:40-46 / PIL."""
+    import re
+    import numpy as np
+    from lavender_amd import _lib, data as D
+    from oracle import pipeline_ref as PR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "lavender_pipeline.h")).read()
+    declared = set(re.findall(r"\b(lav_[a-z0-9_]+)\s*\(", hdr)) - {"lav_last_error"}
+    assert declared == set(_lib.PIPELINE_EXPORTS), declared ^ set(_lib.PIPELINE_EXPORTS)
+    tsvp, idxp = os.path.join(golden_dir, "msrvtt_2rows.tsv"), os.path.join(golden_dir, "msrvtt_2rows.lineidx")
+    for idx in (idxp, None):                               # with the reference's .lineidx, and indexing the lines itself
+        tsv = D.TsvFile(tsvp, idx)
+        assert len(tsv) == 2
+        for r in range(2):
+            ref = PR.read_row(tsvp, tsv.offset(r))
+            assert tsv.seek(tsv.offset(r)) == ref
+            for b in tsv.fields(tsv.offset(r))[1:]:
+                assert D.jpeg_size(b) == (320, 240)
+        tsv.close()
+    g = np.load(os.path.join(golden_dir, "pipeline_frames.npz"))
+    import base64
+    for name in g["syn_names"].tolist():
+        h, w = g[f"syn_{name}_rgb"].shape[:2]
+        assert D.jpeg_size(base64.b64encode(g[f"syn_{name}_jpg"].tobytes())) == (w, h)
+    # frame choice and resize geometry (dataset.py:188-216, torchvision Resize(int))
+    import random
+    from tests.helpers import Tok
+    ds = D.Dataset_Base(type("A", (), dict(size_img=224, img_transform=["img_rand_crop"], size_txt=8))(), "train", 4, Tok())
+    for n in range(1, 12):
+        for cfg in (1, 3, 4, 5):
+            ds.size_frame = cfg
+            random.seed(n * 7 + cfg)
+            a = ds.temporal_sample(list(range(n)), random_sample=True)
+            random.seed(n * 7 + cfg)
+            assert a == PR.temporal_sample(list(range(n)), cfg, True)
+            assert ds.temporal_sample(list(range(n))) == PR.temporal_sample(list(range(n)), cfg)
+    assert D.resized_size(320, 240, 224) == (298, 224) and D.resized_size(240, 320, 224) == (224, 298) and D.resized_size(7, 7, 224) == (224, 224)
