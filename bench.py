@@ -60,6 +60,46 @@ def synth_batch(B, T, S, X, rank, device):
     return dict(img=img, txt=txt, mask=(txt != 0).long())
 
 
+def tsv_feed(args, B, T, rank, world):
+    """Endless batches from the input pipeline over the committed fixture rows (two rows of the reference's sample TSV, T JPEG
+    frames each) replicated to 8 B rows in a scratch TSV -- the on-disk format of _tools/extract_tsv.py, captions from the ids."""
+    import tempfile
+    from lavender_amd import data as D
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "tests", "golden", "msrvtt_2rows.tsv")
+    rows = [ln.rstrip("\n").split("\t") for ln in open(src)]
+    assert all(len(r) - 1 >= T for r in rows), "fixture rows hold 5 frames"
+    d = tempfile.mkdtemp(prefix="lav_bench_tsv_")
+    txt = {}
+    with open(f"{d}/data.tsv", "w") as f, open(f"{d}/data.lineidx", "w") as fi:
+        for i in range(8 * B):
+            r = rows[i % len(rows)]
+            fi.write("%d\n" % f.tell())
+            f.write("\t".join([f"clip{i}"] + r[1:1 + T]) + "\n")
+            txt[f"clip{i}"] = [f"a person is doing something in clip number {i} of the set"]
+
+    class WordTok:
+        cls_token = "[CLS]"; sep_token = "[SEP]"; pad_token = "[PAD]"; mask_token = "[MASK]"; unk_token = "[UNK]"
+        ids = {"[PAD]": 0, "[UNK]": 100, "[CLS]": 101, "[SEP]": 102, "[MASK]": 103, "true": 2995, "false": 6270}
+
+        def convert_tokens_to_ids(self, toks):
+            return [self.ids[t] for t in toks]
+
+        def encode(self, s, padding=None, max_length=None, truncation=None):
+            ids = [101] + [1000 + (hash(w) % 20000) for w in s.split()][:max_length - 2] + [102]
+            return ids + [0] * (max_length - len(ids))
+    args.size_frame, args.img_transform, args.n_workers, args.distributed = T, ["img_rand_crop"], 8, world > 1
+    ds = D.Dataset_Pretrain(args, {"train": txt}, f"{d}/data.tsv", f"{d}/data.lineidx", split="train", dataset="fixture", tokzr=WordTok())
+    dl = D.PretrainLoader(ds, args, rank=rank, world=world)
+    ep = 0
+    while True:
+        dl.sampler.set_epoch(ep)
+        for b in dl:
+            if b["img"].shape[0] == B:
+                yield b
+        ep += 1
+
+
 def cpu_baseline_child():
     """Reference CPU path (restated: oracle/lavender_ref.py, parity-pinned to the real reference), Swin-B + 12L,
     B=2, fp32, forward + loss + backward, on this box's host cores.  Bounded: 1 warm-up + 2 timed iterations.
@@ -125,6 +165,10 @@ def main():
                     help="side measurement at --gpus 1: join a 1-rank RCCL process group and attach the gradient reducer (what the "
                          "overlap bookkeeping and the comm-stream events cost when there is nobody to talk to)")
     ap.add_argument("--zero1", action="store_true", help="side measurement: args.deepspeed = True (ZeRO-1 reducer)")
+    ap.add_argument("--input", default="resident", choices=["resident", "tsv"],
+                    help="side measurement 'tsv': every step pulls its batch through the input pipeline (TSV rows of base64 JPEG frames "
+                         "-> host Huffman decode -> GPU IDCT / resize / crop / normalise, prefetched) and masks it on the host, inside "
+                         "the timed region; the contract value keeps inputs resident in HBM")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_only:
@@ -220,10 +264,19 @@ def main():
             b.update(agent.masking(b["txt"], b["mask"]))
         batches.append(agent.prepare_batch(b))
     np.random.seed(88)
+    feed = None
+    if a.input == "tsv":
+        assert not retrieval, "--input tsv is wired for the pretrain workloads"
+        args.size_txt = X
+        feed = tsv_feed(args, B, T, rank, world)
 
     def run_step(i):
         if retrieval:
             return {"mtm": agent.step(batches[i % nb], True)}
+        if feed is not None:
+            b = next(feed)
+            b.update(agent.masking(b["txt"], b["mask"]))
+            return agent.step(agent.prepare_batch(b), True, sync=False)
         return agent.step(batches[i % nb], True, sync=False)
 
     def barrier():
@@ -335,7 +388,9 @@ def main():
         out = {"metric": "video-text samples/sec (node) pretrain step, Swin-B 5x224^2 + 32-tok", "value": round(value, 2),
                "unit": "samples/s", "n_gpus": world, "world_size_observed": (dist.get_world_size() if world > 1 else 1),
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "ms_per_step_median_hip_events": round(ms_median, 2),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "data": "synthetic" if a.input == "resident" else "SIDE CASE input pipeline in the timed region: fixture JPEG frames (320x240, "
+                       "replicated rows) read from a TSV, decoded / resized / cropped on the GPU, host masking, per step",
                "config": {"workload": f"{what_dp}{what}Swin-{a.size}-K600-22k + {a.layers}-layer fusion + MLM head, "
                                       f"{'main_retrieval_mlm' if retrieval else 'main_pretrain_mlm'} path, "
                                       f"fwd+bwd+clip+AdamW, dropout 0.1 / drop-path 0.2 on",

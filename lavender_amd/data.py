@@ -64,7 +64,7 @@ class TsvFile:
         return [C.string_at(p, n).decode() if n else "" for p, n in self.fields(pos)]
 
     def close(self):
-        if self._h:
+        if self._h and L is not None:                      # L is None during interpreter shutdown
             L.lib.lav_tsv_close(self._h)
             self._h = None
 
@@ -143,7 +143,7 @@ class FrameDecoder:
         return np.frombuffer(buf, dtype=np.uint8, count=3 * w.value * h.value).reshape(h.value, w.value, 3).copy()
 
     def close(self):
-        if self._h:
+        if self._h and L is not None:
             L.lib.lav_decoder_destroy(self._h)
             self._h = None
 
@@ -309,7 +309,7 @@ class _Sampler:
 
 
 class PretrainLoader:
-    """get_dl (dataset.py:279-292) for Dataset_Pretrain: batches {"img": (B, T, 3, S, S) fp32, "txt", "mask"} on the GPU.
+    """get_dl (dataset.py:279-292) for Dataset_Pretrain: batches {"img": (B, T, 3, S, S) fp32 in HBM, "txt", "mask" pinned host}.
     One batch is decoded ahead on a side stream by a prefetch thread (n_workers = host decode threads)."""
 
     def __init__(self, ds, args, rank=0, world=1, prefetch=True):
@@ -325,7 +325,8 @@ class PretrainLoader:
     def _collate(self, items, stream):
         S, T = int(self.args.size_img), max(len(p) for p, _, _ in items if p is not None) if any(p for p, _, _ in items) else self.ds.size_frame
         B = len(items)
-        img = torch.empty((B, T, 3, S, S), dtype=torch.float32, device="cuda")
+        with torch.cuda.stream(stream):                    # owned by the side stream's pool; the consumer records its own use
+            img = torch.empty((B, T, 3, S, S), dtype=torch.float32, device="cuda")
         plans, slots = [], []
         for b, (p, _, _) in enumerate(items):
             if p is None or len(p) != T:
@@ -338,12 +339,12 @@ class PretrainLoader:
             slots += [b * T + t for t in range(T)]
         if plans:
             self.decoder.decode(plans, S, out=img, slots=slots, stream=stream)
-        txt = torch.stack([t for _, t, _ in items]).pin_memory()
-        mask = torch.stack([m for _, _, m in items]).pin_memory()
-        with torch.cuda.stream(stream):
-            batch = {"img": img, "txt": txt.cuda(non_blocking=True), "mask": mask.cuda(non_blocking=True)}
-            ev = torch.cuda.Event()
-            ev.record(stream)
+        # txt / mask stay on the host (pinned), as the reference's DataLoader hands them over: the trainer masks them on the
+        # CPU before the copy (main_pretrain_mlm.py:215-220)
+        batch = {"img": img, "txt": torch.stack([t for _, t, _ in items]).pin_memory(),
+                 "mask": torch.stack([m for _, _, m in items]).pin_memory()}
+        ev = torch.cuda.Event()
+        ev.record(stream)
         return batch, ev
 
     def _batches(self):
@@ -388,8 +389,7 @@ class PretrainLoader:
             batch, ev = got
             cur = torch.cuda.current_stream()
             cur.wait_event(ev)
-            for t in batch.values():
-                t.record_stream(cur)
+            batch["img"].record_stream(cur)
             yield batch
         th.join()
 

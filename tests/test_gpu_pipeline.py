@@ -134,9 +134,11 @@ def test_train_sample_plan_and_loader(gold, golden_dir):
         ds.set_rng(random.Random(11), g)
         torch.manual_seed(3)                               # RandomSampler order
         dl = D.PretrainLoader(ds, args, prefetch=prefetch)
-        got = [{k: v.clone() for k, v in b.items()} for b in dl]
+        got = []
+        for b in dl:
+            assert b["img"].is_cuda and b["txt"].is_pinned() and b["img"].dtype == torch.float32
+            got.append({k: v.clone() for k, v in b.items()})
         assert len(got) == 1 and got[0]["img"].shape == (2, 4, 3, 224, 224) and got[0]["txt"].shape == (2, 32)
-        assert got[0]["img"].is_cuda and got[0]["txt"].is_cuda and got[0]["img"].dtype == torch.float32
         batches.append(got[0])
     for k in ("img", "txt", "mask"):
         assert torch.equal(batches[0][k], batches[1][k]), k
