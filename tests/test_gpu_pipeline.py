@@ -54,8 +54,6 @@ def test_synthetic_jpegs_decode_and_transforms_bit_exact(gold):
     for name in gold["syn_names"].tolist():
         b64 = base64.b64encode(gold[f"syn_{name}_jpg"].tobytes())
         ref = gold[f"syn_{name}_rgb"]
-        if ref.ndim == 2:
-            ref = np.stack([ref] * 3, -1) if False else ref     # PIL .convert('RGB') already made 3 channels in the fixture
         h, w = ref.shape[:2]
         assert D.jpeg_size(b64) == (w, h)
         for S in (8, 24):
