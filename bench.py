@@ -346,7 +346,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as fh:
                 pm = json.load(fh)
             if a.workload == "cfg2" and B == 32 and a.layers == 12 and a.size == "base":
                 traffic = pm["hbm_bytes_per_launch"]
@@ -360,7 +360,7 @@ def main():
         roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T and input-gradient dy.(W^T)^T GEMMs: gemm_huge/big/gemm_kernel<NT>)",
                 "achieved": round(fl / tm / 1e12, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tm / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.md)",
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_hbm_traffic.md)",
                 "algorithmic_bytes_per_launch": round(nb / n),
                 "launches_per_step": n, "avg_launch_us": round(tm / n * 1e6, 2), "avg_launch_gflop": round(fl / n / 1e9, 3),
                 "note": "achieved / avg_launch_us are measured in the shipped configuration, where weight-gradient GEMMs of a second "

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 const char* lav_last_error(void);
-int lav_abi_version(void);
+int lav_abi_version(void);   /* 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM with fused epilogue.  Replaces every nn.Linear on the path (video_swin.py:73-79,137-139,
