@@ -278,6 +278,33 @@ class Dataset_Pretrain(Dataset_Base):
         return plans, txt, mask
 
 
+def reference_paths(dataset, split, part, data_dir):
+    """(tsv, lineidx) file names of main_pretrain_task_specific.py:29-70 for a dataset / split / part."""
+    if dataset == "webvid10m":
+        base = f"{data_dir}/_webvid10m-tsv_frame4/webvid10m-{part + 1:03d}.img" if split == "train" else f"{data_dir}/webvid2.5m_val"
+    elif dataset == "webvid10m_filtered":
+        base = f"{data_dir}/image-1{part:04d}" if split == "train" else f"{data_dir}/webvid2.5m_val"
+    elif dataset == "cc12m":
+        base = f"{data_dir}/train.{part}.62.img" if split == "train" else f"{data_dir}/cc3m_val"
+    else:
+        base = f"{data_dir}/{dataset}_train_{part}" if split == "train" else f"{data_dir}/{dataset}_val"
+    return base + ".tsv", base + ".lineidx"
+
+
+class Dataset_Pretrain_MLM(Dataset_Pretrain):
+    """main_pretrain_mlm.py:15-25: the text gets one [MASK] appended (the VTM answer slot), so txt has size_txt + 1 tokens.
+    Constructor arguments as in the reference; the files are located with its naming scheme."""
+
+    def __init__(self, args, txt, dataset, split, part=None, data_dir=None, tokzr=None):
+        tsv, idx = reference_paths(dataset, split, part, data_dir if data_dir is not None else args.data_dir)
+        super().__init__(args, txt, tsv, idx, split=split, dataset=dataset, tokzr=tokzr)
+        self.part, self.data_dir = part, data_dir if data_dir is not None else args.data_dir
+
+    def str2txt(self, s):
+        txt, mask = super().str2txt(s)
+        return self.append_mask_tok2txt(txt, mask)
+
+
 class _Sampler:
     """dataset.py:279-287: DistributedSampler(shuffle=train) / RandomSampler / SequentialSampler index order."""
 

@@ -2,10 +2,13 @@
 
     python -m torch.distributed.run --nproc_per_node=N main_pretrain_mlm.py --config _args/args_pretrain_webvid.json --path_output D [--path_ckpt P]
 
-The model / agent / optimizer / data-parallel path are the MI355X-native ones of lavender_amd.  The reference's TSV
-datasets and tokenizer download are outside the hot path: without `--data_dir` holding real
-data this script trains on synthetic clips of the configured shape, which is what the benchmark uses.
+The model / agent / optimizer / data-parallel path are the MI355X-native ones of lavender_amd.  When `--data_dir` holds the
+reference's files (`txt_<dataset>.json`, `<dataset>_train_<part>.tsv/.lineidx`, `<dataset>_val.tsv/.lineidx`) and `--tokenizer`
+is a local tokenizer directory, the batches come from the GPU input pipeline (lavender_amd/data.py: TSV -> JPEG decode ->
+transforms in HBM), loop structure as main_pretrain_mlm.py:251-328; otherwise (no data here, no network for the tokenizer) the
+script trains on synthetic clips of the configured shape, which is what the benchmark uses.
 """
+import json
 import os
 
 import numpy as np
@@ -43,8 +46,55 @@ class SyntheticPretrain(torch.utils.data.Dataset):
         return {"img": img, "txt": txt, "mask": (txt != 0).long()}
 
 
+def real_data(args):
+    """{dataset: txt json} and a tokenizer when the reference's data layout is present, else None."""
+    data_dir = getattr(args, "data_dir", None)
+    if not data_dir or not all(os.path.exists(f"{data_dir}/txt_{d}.json") for d in args.dataset) or not os.path.isdir(str(args.tokenizer)):
+        return None
+    import transformers
+    return ({d: json.load(open(f"{data_dir}/txt_{d}.json")) for d in args.dataset},
+            transformers.AutoTokenizer.from_pretrained(args.tokenizer))
+
+
+def train_on_tsv(args, txt_data, tokzr):
+    """main_pretrain_mlm.py:251-328 with the GPU input pipeline."""
+    from lavender_amd.data import Dataset_Pretrain_MLM, get_dl
+    rank, world = get_rank(), get_world_size()
+    loaders, n = {}, 0
+    for d in args.dataset:
+        size_part = args.size_part if isinstance(args.size_part, int) else args.size_part[d]
+        loaders[f"{d}-val"] = get_dl(Dataset_Pretrain_MLM(args, txt_data[d], d, "val", data_dir=args.data_dir, tokzr=tokzr), args, rank, world)
+        loaders[f"{d}-train-0"] = get_dl(Dataset_Pretrain_MLM(args, txt_data[d], d, "train", 0, data_dir=args.data_dir, tokzr=tokzr), args, rank, world)
+        n += len(loaders[f"{d}-train-0"]) * size_part
+    args.max_iter = n * args.size_epoch
+    model = LA.LAVENDER_Pretrain_MLM(args, tokzr)
+    model.load_ckpt(args.path_ckpt)
+    model.cuda()
+    agent = LA.Agent_Pretrain_MLM(args, model)
+    if args.distributed:
+        agent.prepare_dist_model()
+    agent.save_training_meta()
+    for e in range(args.size_epoch):
+        for d in args.dataset:
+            size_part = args.size_part if isinstance(args.size_part, int) else args.size_part[d]
+            for part in range(size_part):
+                key = f"{d}-train-{part}"
+                dl_tr = loaders.get(key) or get_dl(Dataset_Pretrain_MLM(args, txt_data[d], d, "train", part, data_dir=args.data_dir, tokzr=tokzr),
+                                                   args, rank, world)
+                dl_tr.sampler.set_epoch(e + 1)
+                ls_tr = agent.go_dl(e + 1, dl_tr, True)
+                ac_vl = agent.go_dl(e + 1, loaders[f"{d}-val"], False)
+                agent.save_model(e + 1)
+                if is_main_process():
+                    print(f"Ep {e + 1}, dataset {d}, part {part}: {json.dumps(ls_tr)}, {json.dumps(ac_vl)}")
+
+
 if __name__ == '__main__':
     args = get_args()
+    real = real_data(args)
+    if real is not None:
+        train_on_tsv(args, *real)
+        raise SystemExit(0)
     tokzr = _Tok()
     n_steps = int(os.environ.get("LAV_SYNTH_STEPS", 20))
     ds = SyntheticPretrain(args, n_steps * args.size_batch * get_world_size())

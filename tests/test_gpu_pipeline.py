@@ -150,3 +150,38 @@ def test_decoder_rejects_bad_input():
         dec.decode([D.FramePlan(base64.b64encode(b"not a jpeg at all"), 0, 0, 8, 8, 0, 0)], 8)
     with pytest.raises(LavenderHipError):
         D.jpeg_size(b"")
+
+
+def test_agent_trains_and_evaluates_from_the_tsv_loader(tmp_path, golden_dir):
+    """End to end as main_pretrain_mlm.py:251-328 drives it: Dataset_Pretrain_MLM over files named by the reference's scheme,
+    the prefetching GPU loader, host masking, prepare_batch, step (train) and the eval branch, on the micro model."""
+    import json
+    import lavender_amd as LA
+    from lavender_amd import data as D
+    from tests.helpers import make_args
+    rows = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(golden_dir, "msrvtt_2rows.tsv"))]
+    txt = {"train": {}, "val": {}}
+    for split, n in (("train_0", 6), ("val", 2)):
+        with open(tmp_path / f"fix_{split}.tsv", "w") as f, open(tmp_path / f"fix_{split}.lineidx", "w") as fi:
+            for i in range(n):
+                r = rows[i % 2]
+                fi.write("%d\n" % f.tell())
+                f.write("\t".join([f"{split}_{i}"] + r[1:]) + "\n")
+                txt[split.split("_")[0]][f"{split}_{i}"] = [f"clip {i} shows a person doing thing number {i}"]
+    (tmp_path / "txt_fix.json").write_text(json.dumps(txt))
+    args = make_args("micro", "micro", 2, size_txt=15, size_frame=4, img_transform=["img_rand_crop"], n_workers=2, data_dir=str(tmp_path),
+                     distributed=False, max_iter=10)
+    tok = WordTok()
+    assert D.reference_paths("fix", "train", 0, str(tmp_path))[0].endswith("fix_train_0.tsv")
+    ds_tr = D.Dataset_Pretrain_MLM(args, txt, "fix", "train", 0, data_dir=str(tmp_path), tokzr=tok)
+    ds_vl = D.Dataset_Pretrain_MLM(args, txt, "fix", "val", data_dir=str(tmp_path), tokzr=tok)
+    assert len(ds_tr) == 6 and len(ds_vl) == 2
+    _, t, m = ds_tr[0]
+    assert t.shape == (16,) and int(t[-1]) == 103 and int(m[-1]) == 1          # [MASK] appended: the VTM answer slot
+    torch.manual_seed(0)
+    model = LA.LAVENDER_Pretrain_MLM(args, tok).cuda()
+    agent = LA.Agent_Pretrain_MLM(args, model)
+    ls = agent.go_dl(1, D.get_dl(ds_tr, args), True)
+    ac = agent.go_dl(1, D.get_dl(ds_vl, args), False)
+    print("train", ls, "eval", ac)
+    assert all(np.isfinite(v) for v in ls.values()) and set(ls) == {"mtm", "vtm"} and set(ac) == {"mtm", "vtm"}
