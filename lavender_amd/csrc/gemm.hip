@@ -32,6 +32,7 @@ struct GemmArgs {
     float* ws;            // split-K partial tiles [split][tile][128][128] fp32 (out_mode 2, splits > 1), or NULL
     int ws_tiles;         // tiles per split in ws
     int owner;            // out_mode 2 with one block per output tile: plain read-modify-write instead of atomics
+    int dbg;              // probe builds only (lav_gemm_select(5, v)): 1 = return before the epilogue (wrong results), 2 = skip the k-loop
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -817,7 +818,7 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < ((g.dbg & 2) ? 0 : nk); ++kt) {
         const char* la = smem + (kt & 1) * HUGE_STAGE;
         const char* lb = la + 32768;
         if (kt + 1 < nk) issue(kt + 1);
@@ -861,6 +862,7 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
             }
     }
 
+    if (g.dbg & 1) return;
     if constexpr (NW == 8 && F != EF_ALL && F != EF_TNFLUSH) {
         // specialised forward / input-gradient epilogues: every wave stages its own 128 x 64 accumulator block through a
         // private LDS slice in two 64-row halves and stores it -- no block barriers, no waves idling while the other half
@@ -1368,12 +1370,14 @@ static const int lav_gemm_tn_kind = getenv("LAV_GEMM_TN_KIND") ? atoi(getenv("LA
 static const bool lav_gemm_atomic_flush = getenv("LAV_GEMM_ATOMIC_FLUSH") != nullptr;   // test hook: the old atomic split-K flush
 static bool lav_gemm_pp = getenv("LAV_GEMM_PP") ? atoi(getenv("LAV_GEMM_PP")) != 0 : false;   // ping-pong 256x256x32 kernel
 static bool lav_gemm_pp_tn = getenv("LAV_GEMM_PP_TN") ? atoi(getenv("LAV_GEMM_PP_TN")) != 0 : true;   // ping-pong kernel for the 256x256 weight-gradient tiles
+static int lav_gemm_dbg = 0;                               // probe hook: GemmArgs.dbg of the 256x256 kernel
 static int lav_gemm_pp_dbg = 0;                            // ablation builds of the ping-pong kernel (probe only, wrong results): 1 no refills, 2 no fragment reads, 4 no MFMAs
 extern "C" int lav_gemm_select(int which, int value) {    // probe hook (within-process A/B): which 0 = ping-pong kernel on/off; returns the old value
     int old = -1;
     if (which == 0) { old = lav_gemm_pp; lav_gemm_pp = value != 0; }
     if (which == 1) { old = lav_gemm_pp_dbg; lav_gemm_pp_dbg = value; }
     if (which == 2) { old = lav_gemm_pp_tn; lav_gemm_pp_tn = value != 0; }
+    if (which == 5) { old = lav_gemm_dbg; lav_gemm_dbg = value; }
     return old;
 }
 
@@ -1509,6 +1513,7 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
             LAV_LAUNCH_PP(hgrid);
             return lav_check_launch("lav_gemm_bf16");
         }
+        g.dbg = lav_gemm_dbg;
         LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
         return lav_check_launch("lav_gemm_bf16");
     }
