@@ -12,8 +12,10 @@ conversion, antialiased resize, crop and normalisation as HIP kernels writing th
 thread with its own stream keeps one batch ahead of the training step.  The frames are bit-identical to the reference's
 (cv2 / PIL decode + torchvision transforms); tests/test_gpu_pipeline.py holds that against fixtures made with Pillow.
 
-`vid_rand_crop` / `vid_center_crop` (the clip transforms of visbackbone/video_transform.py, not used by the pretrain configs)
-are not implemented and raise.
+The clip transforms `vid_rand_crop` / `vid_center_crop` (visbackbone/video_transform.py) are planned here as well: one target
+size and ONE crop window for all frames of the clip (python `random.randint` for x, then y); their pixel arithmetic is the image
+path's (the reference's `Resize` default 'nearest' selects PIL.Image.BILINEAR through the swapped test at
+video_functional.py:83-86).
 """
 import ctypes as C
 import math
@@ -228,25 +230,48 @@ class Dataset_Base:
             i = torch.randint(0, rh - S + 1, size=(1,), generator=self._torch_gen).item()
             j = torch.randint(0, rw - S + 1, size=(1,), generator=self._torch_gen).item()
             return FramePlan(buf, 0, 0, rw, rh, j, i)
-        raise NotImplementedError(f"img_transform {transform!r}: the clip transforms of visbackbone/video_transform.py "
-                                  "(vid_rand_crop / vid_center_crop) are not part of this build")
+        raise ValueError(f"unknown img_transform {transform!r}")
+
+    def _plan_clip(self, bufs, random_crop):
+        """vid_rand_crop / vid_center_crop (dataset.py:132-162): Resize(size_img) with the size rule of video_functional.py:94-101
+        taken from the FIRST frame, one crop window for the whole clip, ClipToTensor, Normalize."""
+        S = int(self.args.size_img)
+        w, h = jpeg_size(bufs[0])
+        if (w <= h and w == S) or (h <= w and h == S):
+            rw, rh = w, h
+        elif w < h:
+            rw, rh = S, int(S * h / w)
+        else:
+            rw, rh = int(S * w / h), S
+        if S > rw or S > rh:
+            raise ValueError(f"Initial image size should be larger then cropped size but got cropped sizes : ({S}, {S}) while initial image is ({rw}, {rh})")
+        if random_crop:
+            assert self.split == "train"
+            x1 = self._py_rng.randint(0, rw - S)
+            y1 = self._py_rng.randint(0, rh - S)
+        else:
+            x1, y1 = int(round((rw - S) / 2.)), int(round((rh - S) / 2.))
+        return [FramePlan(b, 0, 0, rw, rh, x1, y1) for b in bufs]
 
     def get_img_or_video(self, list_of_b):
         """dataset.py:218-256, as a plan: the same frames, transforms and crop offsets (same RNG draws in the same order);
         the pixels are produced by FrameDecoder.decode at batch time."""
         bufs = self.temporal_sample(list_of_b, random_sample=(self.split == "train"))
-        plans = []
-        for b in bufs:
+        choice = []
+        for _ in bufs:
             if self.split == "train":
-                t = self._py_rng.choice(self.args.img_transform)
+                choice.append(self._py_rng.choice(self.args.img_transform))
             elif self.args.img_transform == ["vid_rand_crop"]:
-                t = "vid_center_crop"
+                choice.append("vid_center_crop")
             elif self.args.img_transform == ["pad_resize"]:
-                t = "pad_resize"
+                choice.append("pad_resize")
             else:
-                t = "img_center_crop"
-            plans.append(self._plan_one(b, t))
-        return plans
+                choice.append("img_center_crop")
+        if any(c.startswith("vid_") for c in choice):
+            if len(set(choice)) != 1:                     # the reference would fail in T.cat / Compose on such a mix
+                raise ValueError(f"clip transforms cannot be mixed with per-image transforms inside one clip: {choice}")
+            return self._plan_clip(bufs, choice[0] == "vid_rand_crop")
+        return [self._plan_one(b, c) for b, c in zip(bufs, choice)]
 
 
 class Dataset_Pretrain(Dataset_Base):

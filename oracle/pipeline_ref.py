@@ -8,7 +8,8 @@ What is restated, and against what it is pinned:
   * dataset.py:177-186  str2img: base64 -> cv2.imdecode / PIL.Image.open -> RGB                      -> str2img.  cv2 is absent from
     this image; the function takes the reference's own `except` branch (PIL).  Both go through libjpeg(-turbo) with default
     settings (islow IDCT, fancy upsampling), whose output is bit-identical across builds by design.
-  * dataset.py:107-118,120-130,164-175  pad_resize / img_center_crop / img_rand_crop                 -> same names here.
+  * dataset.py:107-118,120-130,164-175  pad_resize / img_center_crop / img_rand_crop; :132-162 vid_center_crop / vid_rand_crop
+    (visbackbone/video_transform.py Resize / RandomCrop / CenterCrop / ClipToTensor / Normalize)     -> same names here.
     torchvision (v0.11+ semantics: Resize on a PIL image is PIL.Image.resize(BILINEAR), Pad fills 0, CenterCrop rounds with
     Python round(), RandomCrop draws torch.randint for the row then the column, ToTensor = uint8 -> fp32 / 255, Normalize =
     (x - mean) / std in fp32) is NOT installed here, so these few lines are restated from torchvision's published source and
@@ -92,6 +93,42 @@ def img_rand_crop(img, size_img, generator=None):
     return _to_tensor_normalize(img.crop((j, i, j + size_img, i + size_img)))
 
 
+def _clip_resize_crop(imgs, size_img, x1y1):
+    """visbackbone/video_transform.py Resize (size rule video_functional.py:94-101; its default 'nearest' maps to
+    PIL.Image.BILINEAR, video_functional.py:83-86) + one crop window for the clip + ClipToTensor + Normalize -> (T, 3, S, S)."""
+    im_w, im_h = imgs[0].size
+    if not ((im_w <= im_h and im_w == size_img) or (im_h <= im_w and im_h == size_img)):
+        if im_w < im_h:
+            ow, oh = size_img, int(size_img * im_h / im_w)
+        else:
+            oh, ow = size_img, int(size_img * im_w / im_h)
+        imgs = [im.resize((ow, oh), Image.BILINEAR) for im in imgs]
+    im_w, im_h = imgs[0].size
+    x1, y1 = x1y1(im_w, im_h)
+    imgs = [im.crop((x1, y1, x1 + size_img, y1 + size_img)) for im in imgs]
+    clip = torch.stack([torch.from_numpy(np.array(im, np.uint8, copy=True)).permute(2, 0, 1) for im in imgs], 1).float().div(255)   # (C, T, H, W)
+    mean = torch.as_tensor(MEAN, dtype=clip.dtype)
+    std = torch.as_tensor(STD, dtype=clip.dtype)
+    clip.sub_(mean[:, None, None, None]).div_(std[:, None, None, None])
+    return clip.permute(1, 0, 2, 3)
+
+
+def vid_rand_crop(imgs, size_img, rng=random):
+    """dataset.py:147-162: RandomCrop draws x, then y, with python's random."""
+    def pick(w, h):
+        if size_img > w or size_img > h:
+            raise ValueError("Initial image size should be larger then cropped size")
+        x1 = rng.randint(0, w - size_img)
+        y1 = rng.randint(0, h - size_img)
+        return x1, y1
+    return _clip_resize_crop(imgs, size_img, pick)
+
+
+def vid_center_crop(imgs, size_img):
+    """dataset.py:132-145."""
+    return _clip_resize_crop(imgs, size_img, lambda w, h: (int(round((w - size_img) / 2.)), int(round((h - size_img) / 2.))))
+
+
 def sampling(start, end, n):
     """dataset.py:188-194."""
     if n == 1:
@@ -120,22 +157,29 @@ def temporal_sample(list_of_b, size_frame_cfg, random_sample=False, rng=random):
 def get_img_or_video(list_of_b, size_frame, size_img, img_transform, split="train", rng=random, generator=None):
     """dataset.py:218-256 for the per-image transforms: (T, 3, S, S) fp32."""
     bufs = temporal_sample(list_of_b, size_frame, random_sample=(split == "train"), rng=rng)
-    out = []
+    out, raw, t = [], [], None
     for b in bufs:
         img = str2img(b)
         if split == "train":
             t = rng.choice(img_transform)
+        elif img_transform == ["vid_rand_crop"]:
+            t = "vid_center_crop"
         elif img_transform == ["pad_resize"]:
             t = "pad_resize"
         else:
             t = "img_center_crop"
-        if t == "pad_resize":
-            x = pad_resize(img, size_img)
+        if t.startswith("vid_"):
+            raw.append(img)
+        elif t == "pad_resize":
+            out.append(pad_resize(img, size_img).unsqueeze(0))
         elif t == "img_center_crop":
-            x = img_center_crop(img, size_img)
+            out.append(img_center_crop(img, size_img).unsqueeze(0))
         elif t == "img_rand_crop":
-            x = img_rand_crop(img, size_img, generator)
+            out.append(img_rand_crop(img, size_img, generator).unsqueeze(0))
         else:
             raise NotImplementedError(t)
-        out.append(x.unsqueeze(0))
+    if t == "vid_rand_crop":
+        return vid_rand_crop(raw, size_img, rng)
+    if t == "vid_center_crop":
+        return vid_center_crop(raw, size_img)
     return torch.cat(out, 0)

@@ -7,6 +7,7 @@ Writes next to this file:
         tsv_{r}_{f}_rgb_sub / _rgb_sum      decoded RGB frames (sub-sample + byte sum)
         tsv_{r}_{f}_{transform}_sub / _sum  final normalised tensors of the three per-image transforms at size_img 224
         tsv_train_{r}                       a seeded train-mode sample (temporal sampling + mixed transforms + random crops)
+        tsv_vid_train_{r} / tsv_vid_val_{r} the clip transforms vid_rand_crop (seeded) / vid_center_crop
         syn_{i}_jpg / _rgb                  small synthetic JPEGs (4:4:4, 4:2:2, 4:2:0, grey, odd sizes, optimised Huffman
                                             tables, restart markers) and their full decoded frames
         syn_{i}_{transform}_{S}             full final tensors of the transforms on those frames
@@ -96,6 +97,12 @@ def main():
         x = PR.get_img_or_video(item[1:], 4, 224, ["img_rand_crop", "pad_resize", "img_center_crop"], "train", random, g).numpy()
         res[f"tsv_train_{r}_sub"] = sub(x)
         res[f"tsv_train_{r}_sum"] = np.array([x.astype(np.float64).sum(), np.abs(x.astype(np.float64)).sum()])
+        random.seed(9 + r)                                  # the clip transforms (one crop window per clip, python RNG)
+        x = PR.get_img_or_video(item[1:], 4, 224, ["vid_rand_crop"], "train", random, None).numpy()
+        res[f"tsv_vid_train_{r}_sub"] = sub(x)
+        res[f"tsv_vid_train_{r}_sum"] = np.array([x.astype(np.float64).sum(), np.abs(x.astype(np.float64)).sum()])
+        x = PR.get_img_or_video(item[1:], 4, 224, ["vid_rand_crop"], "val", random, None).numpy()
+        res[f"tsv_vid_val_{r}_sub"] = sub(x)
     res["tsv_ids"] = np.array(ids)
     # ---- synthetic JPEGs --------------------------------------------------------------------------------------------------
     names = []

@@ -124,6 +124,23 @@ def test_train_sample_plan_and_loader(gold, golden_dir):
         g.manual_seed(5 + r)
         ref = PR.get_img_or_video(PR.read_row(tsvp, ds.lineidx[r])[1:], 4, 224, args.img_transform, "train", random, g).numpy()
         assert np.array_equal(x, ref)
+    # clip transforms: one window per clip from python's RNG (train), centre window (eval)
+    args_v = _args(img_transform=["vid_rand_crop"])
+    for r in range(2):
+        for split in ("train", "val"):
+            dsv = D.Dataset_Pretrain(args_v, {split: txt["train"]}, tsvp, idxp, split=split, dataset="msrvtt", tokzr=WordTok())
+            random.seed(9 + r)
+            dsv.set_rng(random, None)
+            plans, _, _ = dsv[r]
+            assert len({(p.crop_x, p.crop_y, p.resize_w, p.resize_h) for p in plans}) == 1
+            x = dec.decode(plans, 224).cpu().numpy()
+            assert np.array_equal(sub(x), gold[f"tsv_vid_{split}_{r}_sub"]), (r, split)
+    with pytest.raises(ValueError):
+        dsm = D.Dataset_Pretrain(_args(img_transform=["vid_rand_crop", "pad_resize"]), txt, tsvp, idxp, split="train", dataset="msrvtt", tokzr=WordTok())
+        for seed in range(20):                             # some draw mixes the two kinds inside one clip
+            random.seed(seed)
+            dsm.set_rng(random, None)
+            dsm[0]
     # loader: synchronous vs prefetching, same private seeds
     batches = []
     for prefetch in (False, True):
