@@ -32,7 +32,7 @@ struct GemmArgs {
     float* ws;            // split-K partial tiles [split][tile][128][128] fp32 (out_mode 2, splits > 1), or NULL
     int ws_tiles;         // tiles per split in ws
     int owner;            // out_mode 2 with one block per output tile: plain read-modify-write instead of atomics
-    int dbg;              // probe builds only (lav_gemm_select(5, v)): 1 = return before the epilogue (wrong results), 2 = skip the k-loop
+    int dbg;              // probe only (lav_gemm_select(5, v), wrong results): 1 = return before the epilogue, 2 = skip the k-loop, 4 = skip the epilogue's staging writes
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -871,6 +871,7 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
         float* clw = (float*)smem + wave * (64 * WS);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                     // unrolled: acc[] must be indexed with compile-time constants
+            if (!(g.dbg & 4)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -878,6 +879,7 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         clw[(i * 16 + (lane >> 4) * 4 + r) * WS + j * 16 + (lane & 15)] = acc[h * 4 + i][j][r];
+            }
             __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the slice is only read by this wave
             __builtin_amdgcn_wave_barrier();
             gemm_epilogue<64, 64, F, 8, WS>(g, clw, m0 + wm * 128 + h * 64, n0 + wn * 64, split);

@@ -1,5 +1,6 @@
 """GPU probe: where a 256x256 NT GEMM launch spends its time -- full launch vs no epilogue (lav_gemm_select(5, 1)) vs no k-loop
-(5, 2) vs neither (5, 3: launch + prologue + tile scheduling only)."""
+(5, 2) vs neither (5, 3: launch + prologue + tile scheduling only); (5, 4) keeps everything but the LDS staging writes of the
+epilogue (garbage results) = what the staging itself costs."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -30,11 +31,11 @@ for M, N, Kd, fl in shapes:
     out = torch.empty(M, N, device="cuda", dtype=bf)
     res = {}
     for rnd in range(3):
-        for d in (0, 1, 2, 3):
+        for d in (0, 1, 2, 3, 4):
             L.lib.lav_gemm_select(5, d)
             res.setdefault(d, []).append(run(lambda: K.gemm(0, A, Bm, M, N, Kd, out=out, **kw), 5))
     t = {d: min(v) for d, v in res.items()}
     peak = 2.0 * M * N * Kd / 2.5e9
     print(f"{M:6d} {N:5d} {Kd:5d} {fl:4s} full {t[0]:6.1f} | no epilogue {t[1]:6.1f} | no k-loop {t[2]:6.1f} | neither {t[3]:5.1f} us | MFMA at peak {peak:6.1f} "
-          f"-> k-loop {t[1]-t[3]:6.1f} ({peak/(t[1]-t[3])*100:4.1f} % of peak), epilogue {t[0]-t[1]:6.1f}")
+          f"-> k-loop {t[1]-t[3]:6.1f} ({peak/(t[1]-t[3])*100:4.1f} % of peak), epilogue {t[0]-t[1]:6.1f} of which LDS staging writes {t[0]-t[4]:5.1f}")
 L.lib.lav_gemm_select(5, 0)
