@@ -91,12 +91,11 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 #define LAV_GQ_SCALE 170.66666666666666f
 #define LAV_GQ_OFF 0.25f
 __device__ __forceinline__ uint2 gq_pack8(const float* g) {
+    // one fma + one v_cvt_pk_u8_f32 per element (round to nearest, saturating to 0..255, byte insert)
     uint32_t w[2] = {0u, 0u};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float q = fminf(fmaxf(fmaf(g[k], LAV_GQ_SCALE, LAV_GQ_OFF * LAV_GQ_SCALE + 0.5f), 0.f), 255.f);
-        w[k >> 2] |= (uint32_t)q << (8 * (k & 3));
-    }
+    for (int k = 0; k < 8; ++k)
+        w[k >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g[k], LAV_GQ_SCALE, LAV_GQ_OFF * LAV_GQ_SCALE), (uint32_t)(k & 3), w[k >> 2]);
     return make_uint2(w[0], w[1]);
 }
 __device__ __forceinline__ void gq_unpack8(uint2 u, float* g) {
