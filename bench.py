@@ -402,7 +402,14 @@ def main():
                "roofline": roof}
         if world == 1 and not a.no_cpu_baseline and a.workload == "cfg2":
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        # RCCL prints its version banner through C stdio, which is flushed at exit when stdout is a pipe: push it out first so that
+        # the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
