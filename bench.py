@@ -287,6 +287,11 @@ def main():
     for i in range(a.warmup):
         run_step(i)
     barrier()
+    try:                                                  # RCCL's init banner (NCCL_DEBUG=VERSION in this image) sits in C stdio buffers of EVERY
+        import ctypes                                     # rank until exit when stdout is a pipe: flush it now, long before rank 0's JSON line
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
     evs[0].record()
