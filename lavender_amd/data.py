@@ -194,25 +194,29 @@ class Dataset_Base:
 
     # ---- frames (dataset.py:188-256) -----------------------------------------------------------------------------------
     def sampling(self, start, end, n):
-        if n == 1:
-            return [int(round((start + end) / 2.))]
+        """n evenly spaced integer positions from start to end inclusive (python round(): halves go to the even neighbour); the
+        midpoint for n == 1 (dataset.py:188-194)."""
         if n < 1:
             raise Exception("behaviour not defined for n<2")
-        step = (end - start) / float(n - 1)
-        return [int(round(start + x * step)) for x in range(n)]
+        if n == 1:
+            return [int(round(0.5 * (start + end)))]
+        pitch = (end - start) / float(n - 1)
+        return [int(round(start + i * pitch)) for i in range(n)]
 
     def temporal_sample(self, list_of_b, random_sample=False):
-        max_size_frame = len(list_of_b)
-        if max_size_frame == 1 or self.size_frame == max_size_frame:
+        """Which frames of a row become the clip (dataset.py:196-216): all of them when the row has exactly size_frame frames (or
+        one); otherwise size_frame positions spread over the row -- from a random phase in [0, ceil(total / size_frame)) with that
+        stride in training, over the whole row in evaluation."""
+        total = len(list_of_b)
+        if total == 1 or total == self.size_frame:
             return list_of_b
-        size_frame = min(self.size_frame, max_size_frame)
-        size_clips = int(math.ceil(max_size_frame / size_frame))
+        want = min(self.size_frame, total)
+        stride = int(math.ceil(total / want))
+        first, last = 0, total - 1
         if random_sample:
-            sampled_start = self._py_rng.choice(range(size_clips))
-            sampled_end = min(sampled_start + (size_frame - 1) * size_clips, max_size_frame - 1)
-        else:
-            sampled_start, sampled_end = 0, max_size_frame - 1
-        return [list_of_b[i] for i in self.sampling(sampled_start, sampled_end, size_frame)]
+            first = self._py_rng.choice(range(stride))
+            last = min(first + (want - 1) * stride, total - 1)
+        return [list_of_b[i] for i in self.sampling(first, last, want)]
 
     def _plan_one(self, buf, transform):
         S = int(self.args.size_img)
