@@ -452,6 +452,32 @@ def retrieval_forward(P, batch, size, heads, ids=SPECIAL):
     return out, ans
 
 
+def qa_mlm_forward(P, batch, size, heads):
+    """LAVENDER_QAOE_MLM.forward (main_qaoe_mlm_lsmdc_fib.py:79-93) = LAVENDER_QAMC_MLM.forward (main_qamc_mlm.py:124-140) with
+    task tokens / prompts off: one (video, text) sequence per sample, MLM-head logits over the text positions, labels passed through."""
+    f_img, m_img = enc_video(P, batch["img"], size)
+    f_txt = enc_txt(P, batch["txt"])
+    out = go_cross(P, f_img, m_img, f_txt, batch["mask"], heads)
+    return mlm_head(P, out[:, f_img.shape[1]:]), batch["mask_ans"]
+
+
+def qa_top_k_acc(out, ans, k):
+    """Agent_QAOE_MLM_LSMDC.get_top_k_acc, main_qaoe_mlm_lsmdc_fib.py:115-126."""
+    B = out.shape[0]
+    a = ans[ans != -1].view(-1, 1)
+    o = out[ans != -1].view(a.shape[0], -1)
+    ac = (torch.topk(o, k=k, dim=-1).indices == a).any(dim=-1).float().tolist()
+    return ac + [0.] * (B - len(ac))
+
+
+def qamc_choice_acc(out, ans, ans_tok_ids, ans_idx):
+    """Agent_QAMC_MLM.step, eval branch, main_qamc_mlm.py:160-170."""
+    B = ans.shape[0]
+    p = out[:, :, ans_tok_ids][ans != -1]
+    p = (p / p.sum(dim=-1).view(B, 1)).view(B, -1)
+    return (torch.argmax(p, dim=-1) == ans_idx).float().tolist()
+
+
 def retrieval_eval_feat(P, img, txt, size):
     """LAVENDER_RetrievalMlmEval.forward('feat'), eval_retrieval_mlm.py:19-37: img (B, Clips, T, C, H, W); the
     video features are averaged over the clips of a video."""

@@ -21,12 +21,13 @@ import make_goldens as MG  # noqa: E402
 from make_goldens import R, Tok, make_batch, sub, stats, hf_dir, BERT_CFGS  # noqa: E402
 
 
-def build(ref, cls, swin, bert, B):
+def build(ref, cls, swin, bert, B, **extra):
     os.environ["LAV_SWIN_SIZE"] = swin
     d = hf_dir(bert)
     args = ref.EasyDict(vis_backbone_size="base", size_img=224, vis_backbone_init="random", kinetics=400, txt_backbone=d,
                         txt_backbone_embed_only=True, fusion_encoder=d, fusion_encoder_rand_init=False, use_checkpoint=False,
                         size_patch=32, size_batch=B, tokenizer=d, enable_task_token=False, enable_prompt=False, temp=0.05)
+    args.update(extra)
     m = cls(args, Tok())
     sd = m.state_dict()
     new = {k: R.fill_tensor(k, v.shape) for k, v in sd.items() if v.is_floating_point()}

@@ -302,3 +302,22 @@ def test_swin_pad_branch_gradients(golden_dir):
         for k in g.files:
             if k.startswith(f"{tag}_grad_sub::"):
                 np.testing.assert_allclose(sub(P["enc_img.swin." + k.split("::")[1]].grad, 1024), g[k], atol=2e-5, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["qaoe_micro_b3", "qamc_micro_b3"])
+def test_qa_mlm_variants(golden_dir, name):
+    """LAVENDER_QAOE_MLM (main_qaoe_mlm_lsmdc_fib.py:79-93) / LAVENDER_QAMC_MLM (main_qamc_mlm.py:124-140): logits at sampled
+    vocabulary columns, log-sum-exp, loss, accuracies and every gradient norm against the reference fixture."""
+    g = _load(golden_dir, name)
+    swin, bert, B, S, heads, X = g["meta"].tolist()
+    P, bc = _variant_params(bert, swin)
+    batch = make_batch(int(B), X=int(X), vocab=bc["vocab"], seed=6)
+    batch["txt"], batch["mask"], batch["mask_ans"] = torch.from_numpy(g["txt"]), (torch.from_numpy(g["txt"]) != 0).long(), torch.from_numpy(g["mask_ans"])
+    out, ans = R.qa_mlm_forward(P, batch, swin, int(heads))
+    np.testing.assert_allclose(out[:, :, torch.from_numpy(g["cols"])].detach().numpy(), g["out_cols"], atol=2e-5)
+    np.testing.assert_allclose(torch.logsumexp(out, -1).detach().numpy(), g["out_lse"], atol=2e-5)
+    ls = torch.nn.functional.cross_entropy(out.flatten(0, 1), ans.flatten(), ignore_index=-1)
+    assert abs(ls.item() - g["loss"][0]) < 1e-5
+    assert R.qa_top_k_acc(out.detach(), ans, 1) == g["ac_1"].tolist() and R.qa_top_k_acc(out.detach(), ans, 5) == g["ac_5"].tolist()
+    ls.backward()
+    _check_grads(P, g)
