@@ -13,7 +13,8 @@ from .pretrain_mlm import LAVENDER_Pretrain_MLM, Agent_Pretrain_MLM, masking  # 
 from .pretrain_task_specific import LAVENDER_Pretrain, Agent_Pretrain  # noqa: F401
 from .retrieval_mlm import LAVENDER_Retrieval_MLM, Agent_Retrieval_MLM, LAVENDER_RetrievalMlmEval  # noqa: F401
 from .captioning import LAVENDER_Captioning  # noqa: F401
-from .qa_mlm import LAVENDER_QAOE_MLM, LAVENDER_QAMC_MLM, Agent_QAOE_MLM, Agent_QAMC_MLM  # noqa: F401
+from .qa_mlm import (LAVENDER_QAOE_MLM, LAVENDER_QAMC_MLM, LAVENDER_RetMC_MLM, Agent_QAOE_MLM, Agent_QAMC_MLM,  # noqa: F401
+                     Agent_RetMC_MLM)
 from .agent import Agent_Base, WarmupLinearLR, CrossEntropyIgnore  # noqa: F401
 
 VIOLET_Base = LAVENDER_Base

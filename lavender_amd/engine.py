@@ -377,11 +377,11 @@ class PairSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f_img, f_txt, vi, ti):
         B, Lv, Hd = f_img.shape
-        X = f_txt.shape[1]
+        nt, X = f_txt.shape[0], f_txt.shape[1]             # nt == B on the pre-training path, B * O texts for retrieval multiple choice
         n = len(vi)
         L = Lv + X
         dev = f_img.device
-        src = torch.cat([f_img.reshape(B * Lv, Hd), f_txt.reshape(B * X, Hd)], 0)
+        src = torch.cat([f_img.reshape(B * Lv, Hd), f_txt.reshape(nt * X, Hd)], 0)
         vi = np.asarray(vi, dtype=np.int64)
         ti = np.asarray(ti, dtype=np.int64)
         idx = np.empty((n, L), dtype=np.int32)
@@ -391,17 +391,17 @@ class PairSeqFn(torch.autograd.Function):
         out = K.gather_rows(src, torch.from_numpy(flat).to(dev, non_blocking=True), n * L, Hd)
         if _keep(ctx):
             order = np.argsort(flat, kind="stable").astype(np.int32)
-            start = np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=B * L))]).astype(np.int32)
+            start = np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=B * Lv + nt * X))]).astype(np.int32)
             ctx.csr = (torch.from_numpy(start).to(dev, non_blocking=True), torch.from_numpy(order).to(dev, non_blocking=True))
-            ctx.meta = (B, Lv, X, Hd, n)
+            ctx.meta = (B, Lv, X, Hd, n, nt)
         return out.view(n, L, Hd)
 
     @staticmethod
     def backward(ctx, dout):
-        B, Lv, X, Hd, n = ctx.meta
+        B, Lv, X, Hd, n, nt = ctx.meta
         start, order = ctx.csr
-        d = K.gather_sum_rows(dout.contiguous().view(n * (Lv + X), Hd), start, order, B * (Lv + X), Hd)
-        return d[:B * Lv].view(B, Lv, Hd), d[B * Lv:].view(B, X, Hd), None, None
+        d = K.gather_sum_rows(dout.contiguous().view(n * (Lv + X), Hd), start, order, B * Lv + nt * X, Hd)
+        return d[:B * Lv].view(B, Lv, Hd), d[B * Lv:].view(nt, X, Hd), None, None
 
 
 class RowGatherFn(torch.autograd.Function):

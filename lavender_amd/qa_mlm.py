@@ -5,7 +5,11 @@
     LAVENDER_QAMC_MLM / Agent_QAMC_MLM   main_qamc_mlm.py:109-209                                     multiple choice: question and all
                                          options as ONE text (X = 101), the [MASK] is trained to the option index token
 
-Both run one (video, text) sequence per sample through go_feat -> go_cross -> fc_mtm over the text positions -- the same HIP
+    LAVENDER_RetMC_MLM / Agent_RetMC_MLM main_retmc_mlm.py:70-140                                      retrieval multiple choice: O candidate texts per
+                                         video, each scored true / false at its [MASK]; the video prefix is shared by the O sequences
+                                         through the pair-index gather (the reference expand()s and flattens feat_img)
+
+The first two run one (video, text) sequence per sample through go_feat -> go_cross -> fc_mtm over the text positions -- the same HIP
 kernels as the pre-training path ("they inherit the speed-up because they sit on the same modules").
 Task tokens / prompts (enable_task_token / enable_prompt) are outside the built paths and raise in the base class."""
 import numpy as np
@@ -45,6 +49,61 @@ class LAVENDER_QAOE_MLM(LAVENDER_Base):
 class LAVENDER_QAMC_MLM(LAVENDER_QAOE_MLM):
     """main_qamc_mlm.py:109-140: the multiple-choice model is the same graph (its task-specific `fc` is deleted in favour of the
     MLM head); only the text it is fed and the agent's evaluation differ."""
+
+
+class LAVENDER_RetMC_MLM(LAVENDER_QAOE_MLM):
+    def forward(self, batch):
+        """main_retmc_mlm.py:89-113: txt / mask / mask_ans are (B, O, X); logits (B * O, X, vocab), labels back as (B, O, X)."""
+        img, txt, mask, ans = [batch.get(key) for key in ["img", "txt", "mask", "mask_ans"]]
+        (_B, _T, _, _H, _W), (_, _O, _X) = img.shape, txt.shape
+        _h, _w = _H // 32, _W // 32
+        feat_img, mask_img, feat_txt, mask_txt = self.go_feat(img, txt.flatten(0, 1), mask.flatten(0, 1))
+        ans = ans.flatten(0, 1)
+        ans, mask_txt, feat_txt = self.prepro_txt_inputs(ans, mask_txt, feat_txt, task_name=batch.get("task_name"), prompt=batch.get("prompt"))
+        vi, ti = np.repeat(np.arange(_B), _O), np.arange(_B * _O)       # video i with each of its O texts (expand + flatten, :100-103)
+        out, _ = self.go_cross_pairs(feat_img, mask_img, feat_txt, mask_txt, vi, ti)
+        out = self.fc_mtm(out[:, (1 + _h * _w) * _T:])
+        return out, ans.view(_B, _O, -1)
+
+
+class Agent_RetMC_MLM(Agent_Base):
+    def __init__(self, args, model):
+        super().__init__(args, model)
+        self.log = {'ls_tr': [], 'ac_vl': [], 'ac_ts': []}
+
+    def prepare_batch(self, batch):
+        lab = batch.get("mask_ans")
+        if isinstance(lab, torch.Tensor) and not lab.is_cuda:
+            batch["_n_lab"] = int((lab != -1).sum())
+        return super().prepare_batch(batch)
+
+    def step(self, batch, is_train):
+        """main_retmc_mlm.py:120-140."""
+        self.model.train() if is_train else self.model.eval()
+        n_lab = batch.pop("_n_lab", None) if isinstance(batch, dict) else None
+        with torch.set_grad_enabled(is_train):
+            out, ans = self.forward_step(batch)
+            if is_train:
+                ls = self.loss_func(out.flatten(0, len(out.shape) - 2), ans.flatten(0, 1).flatten(0, 1), n_lab)
+                self.backward_step(ls)
+                return ls.item()
+        _B, _O, _L = ans.shape
+        p_true = out[:, :, self.true_token_id].float()
+        p_false = out[:, :, self.false_token_id].float()
+        out_mtm = p_true / (p_true + p_false)
+        ans_mtm = ans.view(_B * _O, _L)
+        assert ans_mtm.shape == out_mtm.shape
+        out_mtm = torch.argmax(out_mtm[ans_mtm != -1].view(_B, _O), dim=-1)
+        ans_idx = (ans_mtm[ans_mtm != -1].view(_B, _O) == self.true_token_id).nonzero()[:, 1]
+        return (out_mtm == ans_idx).float().tolist()
+
+    def go_dl(self, ep, dl, is_train):
+        self.model.train() if is_train else self.model.eval()
+        ret = []
+        for batch in dl:
+            r = self.step(self.prepare_batch(dict(batch)), is_train)
+            ret.extend(r) if isinstance(r, list) else ret.append(r)
+        return self.reduce_mean(float(np.average(ret)))
 
 
 class Agent_QAOE_MLM(Agent_Base):

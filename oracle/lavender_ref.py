@@ -461,6 +461,26 @@ def qa_mlm_forward(P, batch, size, heads):
     return mlm_head(P, out[:, f_img.shape[1]:]), batch["mask_ans"]
 
 
+def retmc_mlm_forward(P, batch, size, heads):
+    """LAVENDER_RetMC_MLM.forward, main_retmc_mlm.py:89-113: txt / mask / mask_ans (B, O, X); every video with each of its O texts."""
+    txt, mask, ans = batch["txt"], batch["mask"], batch["mask_ans"]
+    B, O, X = txt.shape
+    f_img, m_img = enc_video(P, batch["img"], size)
+    f_txt = enc_txt(P, txt.flatten(0, 1))
+    vi = np.repeat(np.arange(B), O)
+    out = go_cross(P, f_img[vi], m_img[vi], f_txt, mask.flatten(0, 1), heads)
+    return mlm_head(P, out[:, f_img.shape[1]:]), ans
+
+
+def retmc_acc(out, ans, ids=SPECIAL):
+    """Agent_RetMC_MLM.step, eval branch, main_retmc_mlm.py:130-140."""
+    B, O, L = ans.shape
+    p = out[:, :, ids["true"]] / (out[:, :, ids["true"]] + out[:, :, ids["false"]])
+    a = ans.view(B * O, L)
+    pick = torch.argmax(p[a != -1].view(B, O), dim=-1)
+    return (pick == (a[a != -1].view(B, O) == ids["true"]).nonzero()[:, 1]).float().tolist()
+
+
 def qa_top_k_acc(out, ans, k):
     """Agent_QAOE_MLM_LSMDC.get_top_k_acc, main_qaoe_mlm_lsmdc_fib.py:115-126."""
     B = out.shape[0]

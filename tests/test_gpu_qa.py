@@ -88,3 +88,51 @@ def test_qa_agents_train_and_evaluate():
         else:
             assert isinstance(ev, list) and len(ev) == B and set(ev) <= {0.0, 1.0}
             assert ev == R.qamc_choice_acc(out, ans, opt_ids, b["ans_idx"])
+
+
+def test_retmc_forward_loss_gradients_and_agent(golden_dir):
+    """LAVENDER_RetMC_MLM: O candidate texts per video through the pair-index gather (no expanded feat_img copies) vs oracle and the
+    reference fixture; Agent_RetMC_MLM trains and returns one hit flag per video."""
+    import lavender_amd as LA
+    from oracle import lavender_ref as R
+    from tests.helpers import Tok, build_filled_model, make_args
+    from lavender_amd.agent import CrossEntropyIgnore
+    g = np.load(os.path.join(golden_dir, "retmc_micro_b2.npz"))
+    swin, bert, B, O, heads, X = g["meta"].tolist()
+    B, O, heads, X = int(B), int(O), int(heads), int(X)
+    bc = BERT_CFGS[bert]
+    P = R.filled_params(swin, hidden=bc["hidden"], layers=bc["layers"], ffn=bc["ffn"], vocab=bc["vocab"])
+    for v in P.values():
+        v.requires_grad_(True)
+    txt = torch.from_numpy(g["txt"])
+    batch = {"img": make_batch(B, vocab=bc["vocab"], seed=13)["img"], "txt": txt, "mask": (txt != 0).long(), "mask_ans": torch.from_numpy(g["mask_ans"])}
+    ref, ans_ref = R.retmc_mlm_forward(P, batch, swin, heads)
+    l_ref = torch.nn.functional.cross_entropy(ref.flatten(0, 1), ans_ref.flatten(), ignore_index=-1)
+    l_ref.backward()
+    P["emb_task"].grad = None
+    m = build_filled_model(swin, bert, B, cls=LA.LAVENDER_RetMC_MLM).eval()
+    m.arena().zero_grad()
+    out, ans = m({k: v.cuda() for k, v in batch.items()})
+    assert out.shape == (B * O, X, bc["vocab"]) and ans.shape == (B, O, X) and (ans.cpu() == batch["mask_ans"]).all()
+    a = out.float().cpu()
+    d = (a - ref).abs()
+    print("retmc logits max", d.max().item(), "mean", d.mean().item())
+    assert d.max() < 3e-2 and d.mean() < 5e-3
+    np.testing.assert_allclose(a[:, :, torch.from_numpy(g["cols"])].detach().numpy(), g["out_cols"], atol=3e-2)
+    ls = CrossEntropyIgnore()(out.flatten(0, 1), ans.flatten(), count=B * O)
+    ls.backward()
+    torch.cuda.synchronize()
+    assert abs(ls.item() - g["loss"][0]) < 1e-2
+    _grad_check(m, P)
+    # agent: train on the same batch, then the eval branch
+    args = make_args("micro", "micro", B, lr=2e-3, max_iter=40, size_vocab=-1)
+    m2 = LA.LAVENDER_RetMC_MLM(args, Tok()).cuda()
+    m2.arena()
+    ag = LA.Agent_RetMC_MLM(args, m2)
+    losses = [ag.step(ag.prepare_batch(dict(batch)), True) for _ in range(10)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 1.0, losses
+    ev = ag.step(ag.prepare_batch(dict(batch)), False)
+    m2.eval()
+    with torch.no_grad():
+        o2, a2 = m2({k: v.cuda() for k, v in batch.items()})
+    assert isinstance(ev, list) and len(ev) == B and ev == R.retmc_acc(o2.float().cpu(), a2.cpu())

@@ -321,3 +321,21 @@ def test_qa_mlm_variants(golden_dir, name):
     assert R.qa_top_k_acc(out.detach(), ans, 1) == g["ac_1"].tolist() and R.qa_top_k_acc(out.detach(), ans, 5) == g["ac_5"].tolist()
     ls.backward()
     _check_grads(P, g)
+
+
+def test_retmc_mlm_variant(golden_dir):
+    """LAVENDER_RetMC_MLM (main_retmc_mlm.py:89-113) + the agent's candidate accuracy (:130-140) against the reference fixture."""
+    g = _load(golden_dir, "retmc_micro_b2")
+    swin, bert, B, O, heads, X = g["meta"].tolist()
+    B, O, heads, X = int(B), int(O), int(heads), int(X)
+    P, bc = _variant_params(bert, swin)
+    txt = torch.from_numpy(g["txt"])
+    batch = {"img": make_batch(B, vocab=bc["vocab"], seed=13)["img"], "txt": txt, "mask": (txt != 0).long(), "mask_ans": torch.from_numpy(g["mask_ans"])}
+    out, ans = R.retmc_mlm_forward(P, batch, swin, heads)
+    np.testing.assert_allclose(out[:, :, torch.from_numpy(g["cols"])].detach().numpy(), g["out_cols"], atol=2e-5)
+    np.testing.assert_allclose(torch.logsumexp(out, -1).detach().numpy(), g["out_lse"], atol=2e-5)
+    ls = torch.nn.functional.cross_entropy(out.flatten(0, 1), ans.flatten(), ignore_index=-1)
+    assert abs(ls.item() - g["loss"][0]) < 1e-5
+    assert R.retmc_acc(out.detach().softmax(-1), ans) == g["acc"].tolist()
+    ls.backward()
+    _check_grads(P, g)
