@@ -79,8 +79,11 @@ class CrossEntropyIgnore:
     """T.nn.CrossEntropyLoss(ignore_index=-1) of agent.py:72 on the HIP engine.  `count` (number of labelled
     rows) may be given when the host already knows it (labels are built on the host)."""
 
+    def __init__(self, keep_logits=False):
+        self.keep_logits = bool(keep_logits)              # args.keep_logits: leave the caller's logits intact in training (one extra copy)
+
     def __call__(self, logits, labels, count=None):
-        return E.CrossEntropyFn.apply(logits, labels, count)
+        return E.CrossEntropyFn.apply(logits, labels, count, self.keep_logits)
 
     def cuda(self):
         return self
@@ -90,7 +93,7 @@ class Agent_Base:
     def __init__(self, args, model):
         super().__init__()
         self.args, self.model = args, model
-        self.loss_func = CrossEntropyIgnore().cuda()
+        self.loss_func = CrossEntropyIgnore(keep_logits=getattr(args, "keep_logits", False)).cuda()
         self.optzr = self.build_optimizer()
         self.lr_scheduler = WarmupLinearLR(self.optzr, args.max_iter)
         self.scaler = None                      # bf16 + fp32 masters: no loss scaling

@@ -619,10 +619,15 @@ class ScoreHeadFn(torch.autograd.Function):
 
 class CrossEntropyFn(torch.autograd.Function):
     """CrossEntropyLoss(ignore_index=-1) (agent.py:72).  Training: the logits buffer is consumed -- it is
-    overwritten in place with d(loss)/d(logits)."""
+    overwritten in place with d(loss)/d(logits) -- unless `keep_logits`, which spends one copy of the logits (312 MB at the
+    benchmark batch) so that the caller's tensor stays readable after the loss (accuracy read-outs, a second loss on the same logits)."""
 
     @staticmethod
-    def forward(ctx, logits, labels, count):
+    def forward(ctx, logits, labels, count, keep_logits=False):
+        if keep_logits and ctx.needs_input_grad[0]:
+            src = logits
+            logits = torch.empty_strided(src.shape, src.stride(), dtype=src.dtype, device=src.device) if src.stride(-1) == 1 else src.clone()
+            logits.copy_(src)
         V = logits.shape[-1]
         f32 = logits.dtype == torch.float32
         assert logits.dim() == 2 and logits.stride(-1) == 1 and (f32 or logits.stride(0) % 8 == 0), \
@@ -643,7 +648,7 @@ class CrossEntropyFn(torch.autograd.Function):
     def backward(ctx, g):
         buf = ctx.grad_buf
         if buf is None:
-            return None, None, None
+            return None, None, None, None
         # d(loss)/d(logits) sits in `buf` for an upstream gradient of 1 (loss = ls_mtm + ls_vtm, main_pretrain_mlm.py:163).
         # Any other upstream scale (gradient accumulation loss / k, loss weights, a GradScaler) is applied by a kernel that
         # reads the scalar on the device -- no host sync; an upstream gradient of exactly 1 costs one load per thread.
@@ -653,7 +658,7 @@ class CrossEntropyFn(torch.autograd.Function):
                 K.scale_by_scalar(buf, n, g.reshape(1).float())
             else:                                          # tiny fp32 score matrices whose size is not a multiple of 8
                 buf.mul_(g)
-        return buf, None, None
+        return buf, None, None, None
 
 
 # Set to True only by a caller that guarantees an upstream gradient of exactly 1 (skips the scale launch above).

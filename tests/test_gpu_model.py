@@ -247,3 +247,33 @@ def test_upstream_gradient_scale_is_honoured_without_host_sync():
     rel = ((grads[1] - 0.25 * grads[0]).norm() / (0.25 * grads[0]).norm()).item()
     print("upstream 0.25 vs 1.0: relative difference of the scaled gradients", rel)
     assert rel < 2e-2 and grads[1].norm() > 0
+
+
+def test_keep_logits_flag_leaves_the_outputs_intact_and_the_gradients_equal():
+    """args.keep_logits: the training loss works on a copy, so out_mtm / out_vtm can still be read afterwards (the reference's
+    nn.CrossEntropyLoss never touches them); losses and gradients are those of the in-place default."""
+    from tests.helpers import Tok, make_args
+    import lavender_amd as LA
+    from lavender_amd.dist import set_seed
+    res = []
+    for keep in (False, True):
+        set_seed(88)
+        args = make_args("micro", "micro", 2, keep_logits=keep)
+        m = LA.LAVENDER_Pretrain_MLM(args, Tok()).cuda().eval()
+        m.arena().zero_grad()
+        ag = LA.Agent_Pretrain_MLM(args, m)
+        b = make_batch(2, vocab=BERT_CFGS["micro"]["vocab"])
+        torch.manual_seed(5)
+        b.update(ag.masking(b["txt"], b["mask"]))
+        np.random.seed(5)
+        out = m(ag.prepare_batch(b))
+        before = out["out_mtm"].float().clone()
+        ls = (ag.loss_func(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten())
+              + ag.loss_func(out["out_vtm"].flatten(0, 1), out["ans_vtm"].flatten()))
+        ls.backward()
+        torch.cuda.synchronize()
+        same = torch.equal(before, out["out_mtm"].float())
+        assert same == keep, "the logits must survive the loss exactly when keep_logits is set"
+        res.append((ls.item(), m.arena().grad.clone()))
+    rel = ((res[0][1] - res[1][1]).norm() / res[0][1].norm()).item()       # atomics make two runs differ in the last bits
+    assert res[0][0] == res[1][0] and rel < 1e-4, rel
