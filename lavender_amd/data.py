@@ -376,7 +376,9 @@ class PretrainLoader:
         self._stream = None
 
     def __len__(self):
-        return -(-len(self.sampler.indices() if self.sampler.distributed else range(len(self.ds))) // int(self.args.size_batch))
+        """Batches per epoch on this rank (the last one may be short: drop_last is False in dataset.py:287-291)."""
+        n = -(-len(self.ds) // self.sampler.world) if self.sampler.distributed else len(self.ds)
+        return -(-n // int(self.args.size_batch))
 
     def _collate(self, items, stream):
         S, T = int(self.args.size_img), max(len(p) for p, _, _ in items if p is not None) if any(p for p, _, _ in items) else self.ds.size_frame

@@ -292,3 +292,31 @@ def test_pipeline_library_exports_and_host_side(golden_dir):
             assert a == PR.temporal_sample(list(range(n)), cfg, True)
             assert ds.temporal_sample(list(range(n))) == PR.temporal_sample(list(range(n)), cfg)
     assert D.resized_size(320, 240, 224) == (298, 224) and D.resized_size(240, 320, 224) == (224, 298) and D.resized_size(7, 7, 224) == (224, 224)
+
+
+def test_loader_sampler_orders_match_torch_samplers():
+    """get_dl's index order (dataset.py:279-287): DistributedSampler(shuffle = train) / RandomSampler / SequentialSampler of torch,
+    reproduced without a Dataset object -- same indices for the same seeds, epochs, ranks."""
+    import torch
+    from torch.utils.data import DistributedSampler, RandomSampler, SequentialSampler
+    from lavender_amd.data import _Sampler
+
+    class DS:
+        def __init__(self, n): self.n = n
+        def __len__(self): return self.n
+        def __getitem__(self, i): return i
+    for n in (1, 7, 10, 33):
+        for world in (1, 2, 4):
+            for rank in range(world):
+                for train in (True, False):
+                    for epoch in (0, 3):
+                        ref = DistributedSampler(DS(n), num_replicas=world, rank=rank, shuffle=train)
+                        ref.set_epoch(epoch)
+                        s = _Sampler(n, train, True, rank, world)
+                        s.set_epoch(epoch)
+                        assert s.indices() == list(ref), (n, world, rank, train, epoch)
+        torch.manual_seed(11)
+        a = list(RandomSampler(DS(n)))
+        torch.manual_seed(11)
+        assert _Sampler(n, True, False).indices() == a
+        assert _Sampler(n, False, False).indices() == list(SequentialSampler(DS(n)))
