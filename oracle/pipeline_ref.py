@@ -15,8 +15,15 @@ What is restated, and against what it is pinned:
     (x - mean) / std in fp32) is NOT installed here, so these few lines are restated from torchvision's published source and
     executed with Pillow + torch on the CPU: the pixel arithmetic is Pillow's and torch's own.
   * dataset.py:188-216  sampling / temporal_sample                                                   -> same names here.
-Parity pin: tests/golden/pipeline_frames.npz is written by tests/golden/make_goldens_pipeline.py from these functions running
-on Pillow in the build container (the reference's dataset.py itself imports torchvision and cv2 and cannot be imported).
+Parity pin (round 3): the reference's dataset.Dataset_Base DOES import in the build container with the stub recipe of
+tests/golden/make_goldens.py (cv2 / torchvision mocked: str2img then takes the reference's own PIL branch; the clip transforms of
+visbackbone/video_transform.py need neither).  tests/golden/make_goldens_pipeline_ref.py runs the REFERENCE's sampling,
+temporal_sample, str2img, vid_center_crop, vid_rand_crop and get_img_or_video(["vid_rand_crop"]) on the fixture rows and writes
+tests/golden/pipeline_ref_pin.npz; tests/test_oracle_golden.py::test_pipeline_oracle_against_the_reference_dataset_class holds this
+module to those vectors (exact).  PINNED: read_row's consumer chain, str2img, sampling, temporal_sample, vid_center_crop,
+vid_rand_crop, get_img_or_video on the clip transforms.  UNPINNED ("restated from torchvision's published source"): pad_resize,
+img_center_crop, img_rand_crop -- they call torchvision.transforms, which is not installed here, so their fixtures in
+tests/golden/pipeline_frames.npz (make_goldens_pipeline.py) come from this module itself.
 """
 import base64
 import io

@@ -339,3 +339,55 @@ def test_retmc_mlm_variant(golden_dir):
     assert R.retmc_acc(out.detach().softmax(-1), ans) == g["acc"].tolist()
     ls.backward()
     _check_grads(P, g)
+
+
+def test_pipeline_oracle_against_the_reference_dataset_class(golden_dir):
+    """oracle/pipeline_ref.py against outputs of the REFERENCE's own dataset.Dataset_Base (sampling, temporal_sample, str2img,
+    vid_center_crop, vid_rand_crop, get_img_or_video with img_transform == ['vid_rand_crop']) captured by
+    tests/golden/make_goldens_pipeline_ref.py on the two fixture rows: integers and decoded bytes bit-exact, fp32 tensors exact."""
+    import random
+    import zlib
+    from oracle import pipeline_ref as PR
+    g = _load(golden_dir, "pipeline_ref_pin")
+
+    def sub(a, n=4096, seed=7):                       # the generator's numpy sub-sampler (helpers.sub is the torch one)
+        flat = np.asarray(a).reshape(-1)
+        return flat[np.random.RandomState(seed + flat.size % 9973).permutation(flat.size)[:n]]
+
+    out, pos = g["sampling_out"], 0
+    for s, e, n in g["sampling_args"].tolist():
+        got = PR.sampling(s, e, n)
+        assert got == out[pos:pos + len(got)].tolist(), (s, e, n)
+        pos += len(got)
+    assert pos == len(out)
+    pe = pt = 0
+    for ci, (L, sf) in enumerate(g["temporal_cases"].tolist()):
+        ne, nt = int(g["temporal_eval_len"][ci]), int(g["temporal_train_len"][ci])
+        assert PR.temporal_sample(list(range(L)), sf, False) == g["temporal_eval_out"][pe:pe + ne].tolist(), (L, sf)
+        random.seed(100 + ci)
+        assert PR.temporal_sample(list(range(L)), sf, True, random) == g["temporal_train_out"][pt:pt + nt].tolist(), (L, sf)
+        pe += ne; pt += nt
+    tsvp = os.path.join(golden_dir, "msrvtt_2rows.tsv")
+    offs = [int(x) for x in open(os.path.join(golden_dir, "msrvtt_2rows.lineidx"))]
+
+    def same(x, name):
+        x = x.numpy()
+        assert np.array_equal(sub(x), g[name + "_sub"]), name
+        assert np.array_equal(np.array([x.astype(np.float64).sum(), np.abs(x.astype(np.float64)).sum()]), g[name + "_sum"]), name
+
+    for r, p in enumerate(offs):
+        frames = PR.read_row(tsvp, p)[1:]
+        for fi, b in enumerate(frames):
+            rgb = np.array(PR.str2img(b))
+            assert list(rgb.shape) == g[f"ref_{r}_{fi}_rgb_shape"].tolist()
+            assert np.array_equal(sub(rgb), g[f"ref_{r}_{fi}_rgb_sub"])
+            assert [int(rgb.astype(np.int64).sum()), zlib.adler32(rgb.tobytes())] == g[f"ref_{r}_{fi}_rgb_sum"].tolist()
+        imgs = [PR.str2img(b) for b in frames[:4]]
+        same(PR.vid_center_crop(list(imgs), 224), f"ref_vid_center_{r}")
+        random.seed(21 + r)
+        same(PR.vid_rand_crop(list(imgs), 224, random), f"ref_vid_rand_{r}")
+        random.seed(9 + r)
+        x = PR.get_img_or_video(frames, 4, 224, ["vid_rand_crop"], "train", random, None)
+        assert list(x.shape) == g[f"ref_sample_train_{r}_shape"].tolist()
+        same(x, f"ref_sample_train_{r}")
+        same(PR.get_img_or_video(frames, 4, 224, ["vid_rand_crop"], "val", random, None), f"ref_sample_val_{r}")
