@@ -776,3 +776,17 @@ extern "C" int lav_attention_bwd(void* stream, const lav_attn_desc* d, const voi
     }
     return lav_check_launch("lav_attention_bwd");
 }
+
+// Bias-table gradient alone (window mode, N <= 256 fast path): needs the forward's lse and the -delta scratch that
+// lav_attention_bwd (called first, with dbias_table = NULL) left behind the lse in the same buffer.  A parameter gradient:
+// the engine issues it on the weight-gradient stream.
+extern "C" int lav_attention_bwd_bias(void* stream, const lav_attn_desc* d, const void* qkv, const void* dout, const float* lse,
+                                      float* dbias_table) {
+    AttnArgs a; int problems = 0;
+    if (int rc = attn_setup(d, a, problems)) return rc;
+    LAV_REQUIRE(qkv && dout && lse && dbias_table, "lav_attention_bwd_bias: null pointer");
+    LAV_REQUIRE(d->mode == 0 && d->comb, "lav_attention_bwd_bias: window mode with the precomputed tables (N <= 256) only");
+    a.qkv = (const bf16_t*)qkv; a.dout = (const bf16_t*)dout; a.lse = (float*)lse; a.dbias = dbias_table;
+    return win_persistent_dbias(stream, a, lse + (size_t)problems * d->heads * a.Npad);
+}
+

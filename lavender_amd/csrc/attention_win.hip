@@ -1,16 +1,31 @@
-// Persistent shifted-window attention for gfx950 (window volume N <= 256, head_dim 32): the Swin hot loop.
+// Persistent shifted-window attention for gfx950 (window volume N <= 256, head_dim 32): the Swin hot loop, round-3 kernels.
 //
-// One 512-thread workgroup (8 waves, two per SIMD) per CU owns a fixed (head, window position) pair and walks the
-// batch: the window position fixes the token-row offsets and the mask type, so
-//   * token rows come from a per-geometry table read ONCE per workgroup (no div/mod chains in the loop),
-//   * the (relative-position bias + shift mask + key padding) term of this wave's 32-query strip sits in
-//     registers as packed bf16 for the whole kernel (forward) or streams from L2 (backward),
-//   * K/V (or Q/dO) of the NEXT window are fetched into registers while the current window is computed and land
-//     in the other half of a double-buffered LDS tile: HBM latency never sits on the critical path,
-//   * the bias gradient (sum over windows of dS) is accumulated in registers across the whole batch walk and
-//     flushed once per workgroup (LDS atomics -> 1521 global atomics), instead of per window.
-// Wave w owns 32-row tile w of the 256-slot window (8 tiles).  Scores use the exp2 domain: the bias tables are
-// pre-multiplied by log2(e).
+// One 512-thread workgroup (8 waves, two per SIMD) per CU owns a fixed (head, window position) pair and walks a slice of the
+// batch; wave w owns the 32-row strip w of the 256-slot window (queries in the forward / dQ pass, keys in the dK / dV pass).
+//
+// What round 2's counters called "waves parked 38-55 %" was one design flaw: ordinary global loads (the bias fragments of every
+// tile, the next sample's q / dO / O rows) were consumed INSIDE the tile loop while the LDS-DMA prefetch of the next sample was in
+// flight.  vmcnt retires in order, so the s_waitcnt in front of every tile's softmax drained the whole prefetch: each sample paid
+// an HBM round trip, each tile an L2 round trip.  A timing ablation of the repaired forward (tools/win_abl_probe.py) then showed
+// the kernels VALU-issue-bound (~150 VALU instructions per 32x32 score tile at ~4.3 cycles each against 128 cycles of MFMA), so:
+//
+//   1. Every per-sample operand (q, k, v, dO, O, lse, delta) arrives by global_load_lds (inline asm, invisible to hipcc's
+//      scoreboard) into LDS and is waited for ONCE per sample (s_waitcnt vmcnt(0) + barrier); between the DMA issue of sample b+1
+//      and that barrier no register-destination global load is consumed.
+//   2. The strip's (bias + shift mask + key padding) tiles stay in registers for the whole batch walk -- as MFMA A-operand
+//      fragments: the bias is ADDED ON THE MATRIX CORES (S += BiasTile . I, two v_mfma_f32_32x32x16_bf16 against identity
+//      fragments), which removes the unpack + add from the VALU stream.  Table entries are pre-divided by the softmax scale, so
+//      the exponent argument is ONE fma per element: exp2(fma(acc, scale * log2 e, -m)).
+//   3. The row sum of P (forward) is one more MFMA against a one-row "ones" fragment; delta[q] enters dP through the C operand
+//      of its MFMA (dP - delta costs nothing); padded queries are masked through lse = +inf.  VALU per score element:
+//      forward fma + exp + 1/2 max3 + 1/2 cvt_pk, backward fma + exp + mul + cvt_pk.
+//   4. K (and Q / dO in the dK / dV pass) has ONE LDS image: the XOR of the 16-byte slot is constant over the four rows a
+//      ds_read_b64_tr_b16 lane group gathers, so the transposing reads and the ds_read_b128 fragment reads share it.
+//   5. The relative-position-bias gradient (sum over windows and batch of dS per offset class: 128 resident accumulators per
+//      wave, the reason the round-2 dQ kernel ran one wave per SIMD with 100 spilled registers) is its own kernel, win_dbias3: a
+//      wave owns (query strip, key half) = 64 accumulators fed by one-hot MFMAs.  It is a parameter gradient, so the engine
+//      issues it on the weight-gradient stream, off the dy -> dx chain (lav_attention_bwd_bias).
+// Scores use the exp2 domain; lse is log2(sum_k 2^v).
 #include "attn_common.h"
 #include <stdlib.h>
 
@@ -21,8 +36,7 @@ struct WinGeo {
     int head, ws, b0, b1, type;
 };
 
-__device__ __forceinline__ bool win_geo(const AttnArgs& a, int bsplit, WinGeo& g) {
-    int wg = blockIdx.x;
+__device__ __forceinline__ bool win_geo(const AttnArgs& a, int bsplit, int wg, WinGeo& g) {
     const int bs = wg % bsplit; wg /= bsplit;
     g.ws = wg % a.nWs; g.head = wg / a.nWs;
     const int per = (a.d.B + bsplit - 1) / bsplit;
@@ -31,131 +45,173 @@ __device__ __forceinline__ bool win_geo(const AttnArgs& a, int bsplit, WinGeo& g
     return g.b0 < g.b1;
 }
 
-__device__ __forceinline__ void unpack16(const uint4& u0, const uint4& u1, float* c) { unpack8(u0, c); unpack8(u1, c + 8); }
+// ---- LDS-DMA: 64 lanes x 16 B -> LDS [dst, dst + 1 KB), lane l at dst + 16 l; source = sbase + voff (bytes) per lane --------
+__device__ __forceinline__ void dma16(unsigned lds_dst, const void* sbase, unsigned voff) {
+    unsigned keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// ------------------------------------------------------------------------------------------------------
-// forward
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void win_fwd_p(AttnArgs a, int bsplit) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][K 16 KB | V 16 KB]
-    WinGeo g;
-    if (!win_geo(a, bsplit, g)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
-    const int N = a.N, C = a.C, ld = 3 * C;
-    const bf16_t* qkv = a.qkv;
-    const float sc = a.d.scale * LOG2E;
+// transposing A-operand read (32 d-values x 16 keys, see tr_frag) from a K-TYPE (slot-swizzled) 64-byte-row image
+__device__ __forceinline__ bf16x8 tr_frag_k32(const char* tile, int key0, int lane) {
+    const int i = lane & 15, dhalf = (lane >> 4) & 1, hi = lane >> 5;
+    const int r = i >> 2, c = i & 3;
+    const int dcol = 16 * dhalf + 4 * c;
+    const int slot = dcol >> 3, sub = (dcol & 7) * 2;
+    const int row0 = key0 + 4 * hi + r;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + krow_off<32>(row0, slot) + sub));
+    s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + krow_off<32>(row0 + 8, slot) + sub));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi4;
+    return u.v;
+}
 
-    int srow[2], sslot[2], srel[2];
+// byte offset (relative to the sample's first token row) of lane `lane`'s 16 bytes of DMA piece t of a [256 rows][64 B] K-type
+// image: piece t covers window rows 16 t .. 16 t + 15; the lane lands on physical slot lane & 3 of row 16 t + (lane >> 2), so
+// it fetches the logical slot that the swizzle stores there.  ld = row stride in elements, col0 = first column of the head.
+__device__ __forceinline__ unsigned dma_off(const int* srel_l, int t, int lane, int ld, int col0) {
+    const int rel = srel_l[t * 16 + (lane >> 2)];
+    const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
+    return (unsigned)((rel * ld + col0 + lslot * 8) * 2);
+}
+
+// B-operand identity fragment of k-slab `slab` (16 of the 32 contraction indices): I[k][j] = (k == j)
+__device__ __forceinline__ bf16x8 ident_frag(int slab, int j, int hi) {
+    float e8[8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + 512 * i;
-        srow[i] = c >> 2; sslot[i] = c & 3;
-        srel[i] = a.d.tok_table[g.ws * 256 + srow[i]];
-    }
+    for (int e = 0; e < 8; ++e) e8[e] = (16 * slab + 8 * hi + e == j) ? 1.f : 0.f;
+    return pack_frag(e8);
+}
+
+__device__ __forceinline__ float xhalf_sum(float v) {        // v + (the other 32-lane half's v of the same column)
+    return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+union Frag { uint4 u; bf16x8 b; };
+
+#define ZERO16 {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
+
+// ------------------------------------------------------------------------------------------------------
+// forward.  LDS: [2][Q 16 KB | K 16 KB | V 16 KB] + token rows 1 KB.
+// ------------------------------------------------------------------------------------------------------
+template <int NT>   // 32-key tiles that hold keys: ceil(N / 32)
+__global__ __launch_bounds__(512) void win_fwd3(AttnArgs a, int bsplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WinGeo g;
+    if (!win_geo(a, bsplit, blockIdx.x, g)) return;
+    constexpr int BUF = 49152;
+    int* srel_l = (int*)(smem + 2 * BUF);
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C, ld = 3 * C;
+    const float sc = a.d.scale * LOG2E;
+    if (tid < 256) { const int rel = a.d.tok_table[g.ws * 256 + tid]; srel_l[tid] = rel < 0 ? 0 : rel; }
     const int q = wave * 32 + j;
     const int qrel = a.d.tok_table[g.ws * 256 + q];
     const bool q_ok = qrel >= 0;
-    const int ntile = (N + 31) >> 5;
-
-    const bf16_t* comb = (const bf16_t*)a.d.comb + (((long)(g.type * a.d.heads + g.head) * 64 + wave * 8) * 64 + lane) * 16;
-
-    uint4 kr[2], vr[2], qn[2];
-    auto load = [&](int b) {
-        const long base = (long)b * a.tps;
+    // the strip's (bias + mask) / scale tiles as MFMA A fragments: 8 registers per key tile, loaded once
+    const bf16_t* comb = (const bf16_t*)a.d.comb + ((long)(g.type * a.d.heads + g.head) * 64 + wave * 8) * 1024 + lane * 8;
+    Frag cb[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { cb[t][0].u = *(const uint4*)(comb + t * 1024); cb[t][1].u = *(const uint4*)(comb + t * 1024 + 512); }
+    const bf16x8 id0 = ident_frag(0, j, hi), id1 = ident_frag(1, j, hi);
+    bf16x8 ones0;                                           // A fragment with ones in row 0 only: D[0][q] = sum_k P[q][k]
+    {
+        float e8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) e8[e] = j == 0 ? 1.f : 0.f;
+        ones0 = pack_frag(e8);
+    }
+    __syncthreads();
+    unsigned offq[2], offk[2], offv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offq[i] = dma_off(srel_l, wave * 2 + i, lane, ld, g.head * HD);
+        offk[i] = offq[i] + 2 * C;
+        offv[i] = offq[i] + 4 * C;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto issue = [&](int b, int buf) {
+        const bf16_t* base = a.qkv + (long)b * a.tps * ld;
+        const unsigned d0 = lds0 + buf * BUF + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            kr[i] = make_uint4(0, 0, 0, 0); vr[i] = kr[i];
-            if (srel[i] >= 0) {
-                const bf16_t* p = qkv + (base + srel[i]) * ld + g.head * HD + sslot[i] * 8;
-                kr[i] = *(const uint4*)(p + C);
-                vr[i] = *(const uint4*)(p + 2 * C);
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qn[ks] = make_uint4(0, 0, 0, 0);
-            if (q_ok) qn[ks] = *(const uint4*)(qkv + (base + qrel) * ld + g.head * HD + ks * 16 + 8 * hi);
+            dma16(d0 + i * 1024, base, offq[i]);
+            dma16(d0 + 16384 + i * 1024, base, offk[i]);
+            dma16(d0 + 32768 + i * 1024, base, offv[i]);
         }
     };
-    auto stash = [&](int buf) {
-        char* Ks = smem + buf * 32768;
-        char* Vs = Ks + 16384;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *(uint4*)(Ks + krow_off<HD>(srow[i], sslot[i])) = kr[i];
-            *(uint4*)(Vs + vrow_off<HD>(srow[i], sslot[i])) = vr[i];
-        }
-    };
-    load(g.b0);
-    stash(0);
+    issue(g.b0, 0);
+    dma_wait_all();
     __syncthreads();
 
     for (int b = g.b0; b < g.b1; ++b) {
         const int cur = (b - g.b0) & 1;
-        const char* Ks = smem + cur * 32768;
-        const char* Vs = Ks + 16384;
-        const bf16x8 qf[2] = {as_bf16x8(qn[0]), as_bf16x8(qn[1])};
-        if (b + 1 < g.b1) load(b + 1);
+        const char* Qs = smem + cur * BUF;
+        const char* Ks = Qs + 16384;
+        const char* Vs = Qs + 32768;
+        if (b + 1 < g.b1) issue(b + 1, cur ^ 1);
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(Qs + krow_off<HD>(q, ks * 2 + hi));
 
-        f32x16 o;
+        f32x16 o = ZERO16, lacc = ZERO16;
+        float m_run = -INFINITY;                           // running row maximum, exp2 domain
+        // one key tile per step; the S tile of step t+1 is issued before the softmax of step t so that the matrix pipe works
+        // under the VALU chain of the same wave.  Online softmax with an exact conditional rescale (wave-uniform branch, rare
+        // after the first tiles).
+        f32x16 sa, sb;
+        auto qk = [&](int t, f32x16& s) {
+            const f32x16 z = ZERO16;
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[t][0].b, id0, z, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[t][1].b, id1, s, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-        float m_run = -INFINITY, l_run = 0.f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half * 4 >= ntile) break;
-            uint4 cb[4][2];                              // this strip's (bias + mask) fragments, L2-resident
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                cb[t][0] = *(const uint4*)(comb + (half * 4 + t) * 1024);
-                cb[t][1] = *(const uint4*)(comb + (half * 4 + t) * 1024 + 8);
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 kf = *(const bf16x8*)(Ks + krow_off<HD>(t * 32 + j, ks * 2 + hi));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
             }
-            f32x16 s[4];
+        };
+        auto soft = [&](int t, const f32x16& s) {
+            float mx = max3f(s[0], s[1], s[2]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int r = 3; r < 15; r += 2) mx = max3f(mx, s[r], s[r + 1]);
+            mx = fmaxf(mx, s[15]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+            if (__any(mx > m_run)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = fast_exp2(m_run - m_new);
+                lacc[0] *= alpha;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-                const int k0 = (half * 4 + t) * 32;
-                if (k0 >= N) continue;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 kf = *(const bf16x8*)(Ks + krow_off<HD>(k0 + j, ks * 2 + hi));
-                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
-                }
+                for (int r = 0; r < 16; ++r) o[r] *= alpha;
+                m_run = m_new;
             }
-            float mx = -INFINITY;
+            const float nm = -m_run;
+            uint32_t pk[8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int kt = half * 4 + t;
-                if (kt * 32 >= N) continue;
-                float c[16];
-                unpack16(cb[t][0], cb[t][1], c);
+            for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack2(fast_exp2(fmaf(s[r], sc, nm)), fast_exp2(fmaf(s[r + 1], sc, nm)));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { s[t][r] = fmaf(s[t][r], sc, c[r]); mx = fmaxf(mx, s[t][r]); }
+            for (int sl = 0; sl < 2; ++sl) {
+                Frag pf; pf.u = make_uint4(pk[4 * sl], pk[4 * sl + 1], pk[4 * sl + 2], pk[4 * sl + 3]);
+                bf16x8 vf = tr_frag_k32(Vs, t * 32 + 16 * sl, lane);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.b, o, 0, 0, 0);
+                lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones0, pf.b, lacc, 0, 0, 0);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = fast_exp2(m_run - m_new);
-            l_run *= alpha;
+        };
+        qk(0, sa);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] *= alpha;
-            m_run = m_new;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int k0 = (half * 4 + t) * 32;
-                if (k0 >= N) continue;
-                float p[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(s[t][r] - m_new); l_run += p[r]; }
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    bf16x8 pf = pack_frag(p + 8 * sl);
-                    bf16x8 vf = tr_frag<HD>(Vs, k0 + 16 * sl, 0, lane);
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o, 0, 0, 0);
-                }
+        for (int t = 0; t < NT; t += 2) {
+            if (t + 1 < NT) qk(t + 1, sb);
+            soft(t, sa);
+            if (t + 1 < NT) {
+                if (t + 2 < NT) qk(t + 2, sa);
+                soft(t + 1, sb);
             }
         }
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        // row 0 of the l tile sits in register 0 of the lower half-wave
+        const float l_tot = __shfl(lacc[0], j, 64);
         const float inv_l = l_tot > 0.f ? 1.f / l_tot : 0.f;
         if (q_ok) {
             const long row = (long)b * a.tps + qrel;
@@ -167,365 +223,286 @@ __global__ __launch_bounds__(512) void win_fwd_p(AttnArgs a, int bsplit) {
                 w.y = pack2(o[r4 * 4 + 2] * inv_l, o[r4 * 4 + 3] * inv_l);
                 *(uint2*)(op + 8 * r4 + 4 * hi) = w;
             }
-            // lse kept in the exp2 domain: log2(sum_k 2^v)
             if (a.lse && hi == 0) a.lse[((long)(b * a.nWs + g.ws) * a.d.heads + g.head) * a.Npad + q] = m_run + log2f(l_tot);
         }
-        if (b + 1 < g.b1) stash(cur ^ 1);
+        dma_wait_all();
         __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
-// backward pass 1: dQ (+ bias-table gradient).  256 threads = 4 waves, ONE per SIMD, so each wave may use the whole
-// 512-register file: wave w owns query tiles w and w+4 and keeps sum_windows dS for both strips (2 x 8 tiles x 16
-// = 256 accumulator registers) resident across the batch walk.  The accumulation itself runs on the matrix cores:
-// dsa += E . dS with E a one-hot (32 x 16) fragment, so it costs no VALU work and the sums live in AGPRs.
-// LDS float atomics are avoided entirely (measured: a 64-lane ds_add_f32 retires in ~200 cycles): the final
-// flush is a half-wave-masked read-modify-write into a wave-private LDS copy of the table.
+// backward pass 1: dQ, and delta[q] = sum_d dO[q,d] O[q,d] (stored NEGATED: it is the C operand of the dP MFMAs of all three
+// backward kernels).  LDS: [2][K 16 KB | V 16 KB | lse 1 KB] + wave-private strips [8][Q 2 KB | dO 2 KB | O 2 KB] + token rows.
+// The strips are single-buffered: a wave copies its strip into registers at the top of a sample and only then issues the DMA
+// of the next sample's strip into the same place.
 // ------------------------------------------------------------------------------------------------------
-// NW = 4: one wave per SIMD, two query tiles per wave (512 registers each).  NW = 8: two waves per SIMD, ONE query tile
-// per wave (<= 256 registers: 128 for the resident dS sums), so the MFMA -> VALU -> MFMA chains of one wave are
-// covered by the other; the two wave groups flush into the same four LDS tables one after the other.
-#ifndef WIN_DQ_NOPREFETCH
-#define WIN_DQ_NOPREFETCH 1
-#endif
-template <bool DBIAS, int NW>
-__global__ __launch_bounds__(NW * 64) void win_dq_p(AttnArgs a, int bsplit, float* delta_out) {
-    constexpr int NQ = 8 / NW;                           // query tiles per wave
-    constexpr bool PREFETCH = NW == 4 && !(DBIAS && WIN_DQ_NOPREFETCH);
-    constexpr int NTHR = NW * 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][K(A) 16K | K(tr) 16K | V(A) 16K] + kcode + 4 x dtbl
+template <int NT>
+__global__ __launch_bounds__(512) void win_dq3(AttnArgs a, int bsplit, float* ndelta_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     WinGeo g;
-    if (!win_geo(a, bsplit, g)) return;
-    int* kcode = (int*)(smem + 2 * 49152);
-    int* srel_l = kcode + 256;
-    float* dtbl_all = (float*)(srel_l + 256);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
-    const int N = a.N, C = a.C, ld = 3 * C;
-    const bf16_t* qkv = a.qkv;
+    if (!win_geo(a, bsplit, blockIdx.x, g)) return;
+    constexpr int BUF = 16384 * 2 + 1024;
+    char* strips = smem + 2 * BUF;
+    int* srel_l = (int*)(strips + 8 * 6144);
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C, ld = 3 * C;
     const float sc = a.d.scale * LOG2E;
-
-    if (DBIAS) for (int r = tid; r < 4 * a.tbl_rows; r += NTHR) dtbl_all[r] = 0.f;
-    if (tid < 256) {
-        const int i = tid;
-        kcode[i] = i < N ? (i / (a.d.cfg_ww * a.d.cfg_wh)) * a.cstride_d + ((i / a.d.cfg_ww) % a.d.cfg_wh) * a.cstride_h + (i % a.d.cfg_ww) : 0;
-        const int rel = a.d.tok_table[g.ws * 256 + i];
-        srel_l[i] = rel < 0 ? 0 : rel;      // padded keys read a valid row: their scores are masked to -inf-like by the bias table
-    }
+    if (tid < 256) { const int rel = a.d.tok_table[g.ws * 256 + tid]; srel_l[tid] = rel < 0 ? 0 : rel; }
+    const int q = wave * 32 + j;
+    const int qrel = a.d.tok_table[g.ws * 256 + q];
+    const bool q_ok = qrel >= 0;
+    const bf16_t* comb = (const bf16_t*)a.d.comb + ((long)(g.type * a.d.heads + g.head) * 64 + wave * 8) * 1024 + lane * 8;
+    Frag cb[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { cb[t][0].u = *(const uint4*)(comb + t * 1024); cb[t][1].u = *(const uint4*)(comb + t * 1024 + 512); }
+    const bf16x8 id0 = ident_frag(0, j, hi), id1 = ident_frag(1, j, hi);
     __syncthreads();
-    int qrel[NQ]; bool q_ok[NQ];
+    unsigned offk[2], offq[2], offg[2];                       // a 256-row image = 16 one-KB pieces: two per wave and operand
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
-        qrel[qi] = a.d.tok_table[g.ws * 256 + (wave + NW * qi) * 32 + j];
-        q_ok[qi] = qrel[qi] >= 0;
+    for (int i = 0; i < 2; ++i) {
+        offk[i] = dma_off(srel_l, wave * 2 + i, lane, ld, C + g.head * HD);
+        offq[i] = dma_off(srel_l, wave * 2 + i, lane, ld, g.head * HD);
+        offg[i] = dma_off(srel_l, wave * 2 + i, lane, C, g.head * HD);
     }
-    const int ntile = (N + 31) >> 5;
-    const bf16_t* comb0 = (const bf16_t*)a.d.comb + ((long)(g.type * a.d.heads + g.head) * 64 * 64 + lane) * 16;
-
-    // one-hot A fragments: E_sl[i][k-slot (hi, e)] = 1 iff i == 16 sl + 8 (e >> 2) + 4 hi + (e & 3)
-    bf16x8 onehot[2];
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        float e8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) e8[e] = (j == 16 * sl + 8 * (e >> 2) + 4 * hi + (e & 3)) ? 1.f : 0.f;
-        onehot[sl] = pack_frag(e8);
-    }
-    f32x16 dsa[NQ][8];
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi)
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dsa[qi][kt][r] = 0.f;
-
-    uint4 qn[NQ][2], gn[NQ][2], on[NQ][2];
-    float lse_n[NQ];
-    // K (two layouts) and V of window b go straight from HBM/L2 into LDS buffer `buf` (global_load_lds, 1 KB per
-    // wave-instruction, no staging registers); the swizzle of the ds_read_b128 layout is applied to the SOURCE slot
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned strip0 = lds0 + 2 * BUF + wave * 6144;
+    const long lse_row = (long)g.ws * a.d.heads + g.head;       // + b * nWs * heads
     auto issue_kv = [&](int b, int buf) {
-        const long base = (long)b * a.tps;
-        char* B0 = smem + buf * 49152;
+        const bf16_t* base = a.qkv + (long)b * a.tps * ld;
+        const unsigned d0 = lds0 + buf * BUF + wave * 2048;
 #pragma unroll
-        for (int i = 0; i < 48 / NW; ++i) {
-            const int t = wave * (48 / NW) + i;
-            const int cpy = t >> 4, chunk = t & 15;
-            const int rel = srel_l[chunk * 16 + (lane >> 2)];
-            const int lslot = cpy == 1 ? (lane & 3) : ((lane & 3) ^ ((lane >> 4) & 3));
-            const bf16_t* src = qkv + (base + rel) * ld + g.head * HD + lslot * 8 + (cpy == 2 ? 2 * C : C);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(B0 + cpy * 16384 + chunk * 1024), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            dma16(d0 + i * 1024, base, offk[i]);
+            dma16(d0 + 16384 + i * 1024, base, offk[i] + 2 * C);
         }
+        if (wave == 0)
+            dma16(lds0 + buf * BUF + 32768, a.lse + ((long)b * a.nWs * a.d.heads + lse_row) * a.Npad, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
     };
-    auto load = [&](int b) {
-        const long base = (long)b * a.tps;
+    auto issue_strip = [&](int b) {
+        const bf16_t* bq = a.qkv + (long)b * a.tps * ld;
+        const bf16_t* bg = a.dout + (long)b * a.tps * C;
+        const bf16_t* bo = a.out + (long)b * a.tps * C;
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                qn[qi][ks] = make_uint4(0, 0, 0, 0); gn[qi][ks] = qn[qi][ks]; on[qi][ks] = qn[qi][ks];
-                if (q_ok[qi]) {
-                    const long row = base + qrel[qi];
-                    const int off = g.head * HD + ks * 16 + 8 * hi;
-                    qn[qi][ks] = *(const uint4*)(qkv + row * ld + off);
-                    gn[qi][ks] = *(const uint4*)(a.dout + row * C + off);
-                    on[qi][ks] = *(const uint4*)(a.out + row * C + off);
-                }
-            }
-            lse_n[qi] = q_ok[qi] ? a.lse[((long)(b * a.nWs + g.ws) * a.d.heads + g.head) * a.Npad + (wave + NW * qi) * 32 + j] : 0.f;
+        for (int i = 0; i < 2; ++i) {
+            dma16(strip0 + i * 1024, bq, offq[i]);
+            dma16(strip0 + 2048 + i * 1024, bg, offg[i]);
+            dma16(strip0 + 4096 + i * 1024, bo, offg[i]);
         }
     };
     issue_kv(g.b0, 0);
-    load(g.b0);
+    issue_strip(g.b0);
+    dma_wait_all();
     __syncthreads();
 
     for (int b = g.b0; b < g.b1; ++b) {
         const int cur = (b - g.b0) & 1;
-        const char* Ks = smem + cur * 49152;
-        const char* Kv = Ks + 16384;
-        const char* Vs = Ks + 32768;
-        if (!PREFETCH && b > g.b0) load(b);
-        bf16x8 qf[NQ][2], dof[NQ][2];
-        float dl[NQ], lse[NQ];
+        const char* Ks = smem + cur * BUF;
+        const char* Vs = Ks + 16384;
+        const float* lse_l = (const float*)(Ks + 32768);
+        const char* Sq = strips + wave * 6144;
+        bf16x8 qf[2], dof[2];
+        float dl = 0.f;
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-            float d = 0.f;
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = krow_off<HD>(j, ks * 2 + hi);
+            Frag fq, fg, fo;
+            fq.u = *(const uint4*)(Sq + off); fg.u = *(const uint4*)(Sq + 2048 + off); fo.u = *(const uint4*)(Sq + 4096 + off);
+            qf[ks] = fq.b; dof[ks] = fg.b;
+            float gf[8], of[8];
+            unpack8(fg.u, gf); unpack8(fo.u, of);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl = fmaf(gf[e], of[e], dl);
+        }
+        dl = xhalf_sum(dl);
+        const float nl = q_ok ? -lse_l[q] : -INFINITY;     // padded query: P = exp2(-inf) = 0
+        if (q_ok && hi == 0) ndelta_out[((long)b * a.nWs * a.d.heads + lse_row) * a.Npad + q] = -dl;
+        f32x16 ndl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ndl[r] = -dl;
+        lds_wait_all();                                      // the strip is in registers: its LDS image may be overwritten
+        if (b + 1 < g.b1) { issue_kv(b + 1, cur ^ 1); issue_strip(b + 1); }
+
+        f32x16 dq = ZERO16;
+        f32x16 sa, sb, pa, pb;
+        auto front = [&](int t, f32x16& s, f32x16& dp) {    // S^T tile (+ bias) and dP^T - delta of key tile t
+            const f32x16 z = ZERO16;
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[t][0].b, id0, z, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[t][1].b, id1, s, 0, 0, 0);
+            dp = ndl;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                qf[qi][ks] = as_bf16x8(qn[qi][ks]); dof[qi][ks] = as_bf16x8(gn[qi][ks]);
-                float gf[8], of[8];
-                unpack8(gn[qi][ks], gf); unpack8(on[qi][ks], of);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d += gf[e] * of[e];
+                const int off = krow_off<HD>(t * 32 + j, ks * 2 + hi);
+                bf16x8 kf = *(const bf16x8*)(Ks + off);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                bf16x8 vf = *(const bf16x8*)(Vs + off);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
             }
-            d += __shfl_xor(d, 32, 64);
-            dl[qi] = d; lse[qi] = lse_n[qi];
-            if (q_ok[qi] && hi == 0)
-                delta_out[((long)(b * a.nWs + g.ws) * a.d.heads + g.head) * a.Npad + (wave + NW * qi) * 32 + j] = d;
-        }
-        if (b + 1 < g.b1) {
-            issue_kv(b + 1, cur ^ 1);
-            if (PREFETCH) load(b + 1);                    // register prefetch of the next window's q / dO / O rows
-        }
-
+        };
+        auto back = [&](int t, const f32x16& s, const f32x16& dp) {
+            uint32_t dk[8];
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-            const int qt = wave + NW * qi;
-            if (qt >= ntile) break;
-            const bf16_t* comb = comb0 + (long)qt * 8 * 1024;
-            f32x16 dq;
+            for (int r = 0; r < 16; r += 2)
+                dk[r >> 1] = pack2(fast_exp2(fmaf(s[r], sc, nl)) * dp[r], fast_exp2(fmaf(s[r + 1], sc, nl)) * dp[r + 1]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 8; ++kt) {
-                if (kt >= ntile) break;
-                const int k0 = kt * 32;
-                const uint4 c0 = *(const uint4*)(comb + kt * 1024), c1 = *(const uint4*)(comb + kt * 1024 + 8);
-                f32x16 s, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 kf = *(const bf16x8*)(Ks + krow_off<HD>(k0 + j, ks * 2 + hi));
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][ks], s, 0, 0, 0);
-                    bf16x8 vf = *(const bf16x8*)(Vs + krow_off<HD>(k0 + j, ks * 2 + hi));
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[qi][ks], dp, 0, 0, 0);
-                }
-                float c[16], ds[16];
-                unpack16(c0, c1, c);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = q_ok[qi] ? fast_exp2(fmaf(s[r], sc, c[r]) - lse[qi]) : 0.f;   // padded keys: c = -inf-like -> 0
-                    ds[r] = p * (dp[r] - dl[qi]);
-                }
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    bf16x8 dsf = pack_frag(ds + 8 * sl);
-                    bf16x8 ktf = tr_frag<HD>(Kv, k0 + 16 * sl, 0, lane);
-                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq, 0, 0, 0);
-                    if (DBIAS) dsa[qi][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(onehot[sl], dsf, dsa[qi][kt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);        // keep each tile's loads next to their use (register pressure)
+            for (int sl = 0; sl < 2; ++sl) {
+                Frag df; df.u = make_uint4(dk[4 * sl], dk[4 * sl + 1], dk[4 * sl + 2], dk[4 * sl + 3]);
+                bf16x8 ktf = tr_frag_k32(Ks, t * 32 + 16 * sl, lane);
+                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, df.b, dq, 0, 0, 0);
             }
-            if (q_ok[qi]) {
-                bf16_t* op = a.dqkv + ((long)b * a.tps + qrel[qi]) * ld + g.head * HD;
+        };
+        front(0, sa, pa);
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    uint2 w;
-                    w.x = pack2(dq[r4 * 4 + 0] * a.d.scale, dq[r4 * 4 + 1] * a.d.scale);
-                    w.y = pack2(dq[r4 * 4 + 2] * a.d.scale, dq[r4 * 4 + 3] * a.d.scale);
-                    *(uint2*)(op + 8 * r4 + 4 * hi) = w;
-                }
+        for (int t = 0; t < NT; t += 2) {
+            if (t + 1 < NT) front(t + 1, sb, pb);
+            back(t, sa, pa);
+            if (t + 1 < NT) {
+                if (t + 2 < NT) front(t + 2, sa, pa);
+                back(t + 1, sb, pb);
             }
         }
-        __syncthreads();                                  // drains the LDS-DMA of window b+1 (vmcnt) and fences buffer reuse
-    }
-    // ---- flush: registers -> wave-private LDS table (index = code(q) - code(k) + const) -> global --------------
-    // Within one half-wave the 32 queries are distinct tokens and the key is fixed, so the 32 indices are distinct:
-    // a plain read-modify-write per half is race-free.  The two halves (key, key + 4) are done one after the other.
-    if (DBIAS) {
-        float* dtbl = dtbl_all + (wave & 3) * a.tbl_rows;
+        if (q_ok) {
+            bf16_t* op = a.dqkv + ((long)b * a.tps + qrel) * ld + g.head * HD;
 #pragma unroll
-        for (int grp = 0; grp < NW / 4; ++grp) {             // wave groups take turns on the four tables
-            if (grp > 0) __syncthreads();
-            if ((wave >> 2) != grp) continue;
-#pragma unroll
-            for (int qi = 0; qi < NQ; ++qi) {
-                const int qt = wave + NW * qi;
-                if (qt >= ntile) break;
-                const int qc = kcode[qt * 32 + j] + a.tbl_const;
-#pragma unroll
-                for (int kt = 0; kt < 8; ++kt) {
-                    if (kt >= ntile) break;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int k = kt * 32 + tile_row(r, hi);
-                        const int idx = qc - kcode[k];
-                        const bool ok = q_ok[qi] && k < N;
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            if (hi == h && ok) dtbl[idx] += dsa[qi][kt][r];
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                    }
-                }
+            for (int r4 = 0; r4 < 4; ++r4) {
+                uint2 w;
+                w.x = pack2(dq[r4 * 4 + 0] * a.d.scale, dq[r4 * 4 + 1] * a.d.scale);
+                w.y = pack2(dq[r4 * 4 + 2] * a.d.scale, dq[r4 * 4 + 3] * a.d.scale);
+                *(uint2*)(op + 8 * r4 + 4 * hi) = w;
             }
         }
+        dma_wait_all();
         __syncthreads();
-        for (int r = tid; r < a.tbl_rows; r += NTHR) {
-            const float v = dtbl_all[r] + dtbl_all[a.tbl_rows + r] + dtbl_all[2 * a.tbl_rows + r] + dtbl_all[3 * a.tbl_rows + r];
-            if (v != 0.f) atomicAdd(a.dbias + (long)r * a.d.heads + g.head, v);
-        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
-// backward pass 2: dK, dV.  Wave owns key tile `wave`; queries / dO of the window are staged in LDS.
+// backward pass 2: dK, dV.  Wave owns key tile `wave`.  LDS: [2][Q 16 KB | dO 16 KB | lse 1 KB | -delta 1 KB] + wave-private
+// strips [8][K 2 KB | V 2 KB] + token rows.  Score tiles are queries x keys here, so lse and delta vary along the registers of
+// a lane: both come from LDS per tile (delta as the C operand of the dP MFMAs, -lse as the addend of the exponent fma).
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void win_dkv_p(AttnArgs a, int bsplit, const float* delta_in) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q(A) | Q(tr) | dO(A) | dO(tr) 16K each | lse 1K | delta 1K]
+template <int NT>
+__global__ __launch_bounds__(512) void win_dkv3(AttnArgs a, int bsplit, const float* ndelta_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     WinGeo g;
-    if (!win_geo(a, bsplit, g)) return;
-    constexpr int BUF = 65536 + 2048;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
+    if (!win_geo(a, bsplit, blockIdx.x, g)) return;
+    constexpr int BUF = 16384 * 2 + 2048;
+    char* strips = smem + 2 * BUF;
+    int* srel_l = (int*)(strips + 8 * 4096);
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.N, C = a.C, ld = 3 * C;
-    const bf16_t* qkv = a.qkv;
     const float sc = a.d.scale * LOG2E;
-
-    int srow[2], sslot[2], srel[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + 512 * i;
-        srow[i] = c >> 2; sslot[i] = c & 3;
-        srel[i] = a.d.tok_table[g.ws * 256 + srow[i]];
-    }
+    if (tid < 256) { const int rel = a.d.tok_table[g.ws * 256 + tid]; srel_l[tid] = rel < 0 ? 0 : rel; }
     const int key = wave * 32 + j;
     const int krel = a.d.tok_table[g.ws * 256 + key];
     const bool k_ok = krel >= 0;
-    const int ntile = (N + 31) >> 5;
-    const bool wave_on = wave < ntile;
-    const bf16_t* combT = (const bf16_t*)a.d.combT + (((long)(g.type * a.d.heads + g.head) * 64 + wave * 8) * 64 + lane) * 16;
-    const int srel_q = tid < 256 ? a.d.tok_table[g.ws * 256 + tid] : -1;
-
-    uint4 qr[2], gr[2], kn[2], vn[2];
-    float lse_r = 0.f, dl_r = 0.f;
-    auto load = [&](int b) {
-        const long base = (long)b * a.tps;
+    const bool wave_on = wave < NT;                         // wave-uniform: key tiles past N carry no keys
+    const bf16_t* combT = (const bf16_t*)a.d.combT + ((long)(g.type * a.d.heads + g.head) * 64 + wave * 8) * 1024 + lane * 8;
+    Frag cb[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { cb[t][0].u = *(const uint4*)(combT + t * 1024); cb[t][1].u = *(const uint4*)(combT + t * 1024 + 512); }
+    const bf16x8 id0 = ident_frag(0, j, hi), id1 = ident_frag(1, j, hi);
+    __syncthreads();
+    unsigned offq[2], offg[2], offk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offq[i] = dma_off(srel_l, wave * 2 + i, lane, ld, g.head * HD);
+        offg[i] = dma_off(srel_l, wave * 2 + i, lane, C, g.head * HD);
+        offk[i] = offq[i] + 2 * C;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned strip0 = lds0 + 2 * BUF + wave * 4096;
+    const long lse_row = (long)g.ws * a.d.heads + g.head;
+    auto issue_q = [&](int b, int buf) {
+        const bf16_t* bq = a.qkv + (long)b * a.tps * ld;
+        const bf16_t* bg = a.dout + (long)b * a.tps * C;
+        const unsigned d0 = lds0 + buf * BUF + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            qr[i] = make_uint4(0, 0, 0, 0); gr[i] = qr[i];
-            if (srel[i] >= 0) {
-                const long row = base + srel[i];
-                qr[i] = *(const uint4*)(qkv + row * ld + g.head * HD + sslot[i] * 8);
-                gr[i] = *(const uint4*)(a.dout + row * C + g.head * HD + sslot[i] * 8);
-            }
+            dma16(d0 + i * 1024, bq, offq[i]);
+            dma16(d0 + 16384 + i * 1024, bg, offg[i]);
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            kn[ks] = make_uint4(0, 0, 0, 0); vn[ks] = kn[ks];
-            if (k_ok) {
-                const bf16_t* p = qkv + (base + krel) * ld + g.head * HD + ks * 16 + 8 * hi;
-                kn[ks] = *(const uint4*)(p + C);
-                vn[ks] = *(const uint4*)(p + 2 * C);
-            }
-        }
-        if (tid < 256) {
-            const long li = ((long)(b * a.nWs + g.ws) * a.d.heads + g.head) * a.Npad + tid;
-            lse_r = srel_q >= 0 ? a.lse[li] : 0.f;
-            dl_r = srel_q >= 0 ? delta_in[li] : 0.f;
-        }
+        const long lo = ((long)b * a.nWs * a.d.heads + lse_row) * a.Npad;
+        if (wave == 0) dma16(lds0 + buf * BUF + 32768, a.lse + lo, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
+        if (wave == 1) dma16(lds0 + buf * BUF + 32768 + 1024, ndelta_in + lo, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
     };
-    auto stash = [&](int buf) {
-        char* B0 = smem + buf * BUF;
+    auto issue_strip = [&](int b) {
+        const bf16_t* bq = a.qkv + (long)b * a.tps * ld;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *(uint4*)(B0 + krow_off<HD>(srow[i], sslot[i])) = qr[i];
-            *(uint4*)(B0 + 16384 + vrow_off<HD>(srow[i], sslot[i])) = qr[i];
-            *(uint4*)(B0 + 32768 + krow_off<HD>(srow[i], sslot[i])) = gr[i];
-            *(uint4*)(B0 + 49152 + vrow_off<HD>(srow[i], sslot[i])) = gr[i];
+            dma16(strip0 + i * 1024, bq, offk[i]);
+            dma16(strip0 + 2048 + i * 1024, bq, offk[i] + 2 * C);
         }
-        if (tid < 256) { ((float*)(B0 + 65536))[tid] = lse_r; ((float*)(B0 + 65536 + 1024))[tid] = dl_r; }
     };
-    load(g.b0);
-    stash(0);
+    issue_q(g.b0, 0);
+    issue_strip(g.b0);
+    dma_wait_all();
     __syncthreads();
 
     for (int b = g.b0; b < g.b1; ++b) {
         const int cur = (b - g.b0) & 1;
         const char* Qs = smem + cur * BUF;
-        const char* Qv = Qs + 16384;
-        const char* Gs = Qs + 32768;
-        const char* Gv = Qs + 49152;
-        const float* qlse = (const float*)(Qs + 65536);
-        const float* qdl = qlse + 256;
-        const bf16x8 kf[2] = {as_bf16x8(kn[0]), as_bf16x8(kn[1])};
-        const bf16x8 vf[2] = {as_bf16x8(vn[0]), as_bf16x8(vn[1])};
-        if (b + 1 < g.b1) load(b + 1);
+        const char* Gs = Qs + 16384;
+        const float* lse_l = (const float*)(Qs + 32768);
+        const float* ndl_l = lse_l + 256;
+        const char* Sk = strips + wave * 4096;
+        bf16x8 kf[2], vf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = krow_off<HD>(j, ks * 2 + hi);
+            kf[ks] = *(const bf16x8*)(Sk + off); vf[ks] = *(const bf16x8*)(Sk + 2048 + off);
+        }
+        lds_wait_all();
+        if (b + 1 < g.b1) { issue_q(b + 1, cur ^ 1); issue_strip(b + 1); }
 
         if (wave_on) {
-            f32x16 dk, dv;
+            f32x16 dk = ZERO16, dv = ZERO16;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
-#pragma unroll
-            for (int qt = 0; qt < 8; ++qt) {
-                if (qt >= ntile) break;
+            for (int qt = 0; qt < NT; ++qt) {
                 const int q0 = qt * 32;
-                const uint4 c0 = *(const uint4*)(combT + qt * 1024), c1 = *(const uint4*)(combT + qt * 1024 + 8);
-                f32x16 s, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 qa = *(const bf16x8*)(Qs + krow_off<HD>(q0 + j, ks * 2 + hi));
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
-                    bf16x8 ga = *(const bf16x8*)(Gs + krow_off<HD>(q0 + j, ks * 2 + hi));
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp, 0, 0, 0);
-                }
-                float c[16], pd[16], ds[16];
-                unpack16(c0, c1, c);
+                const f32x16 z = ZERO16;
+                f32x16 s, dp, nls;
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[qt][0].b, id0, z, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[qt][1].b, id1, s, 0, 0, 0);
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const int qb = q0 + 8 * r4 + 4 * hi;
-                    const float4 l4 = *(const float4*)(qlse + qb);
-                    const float4 d4 = *(const float4*)(qdl + qb);
-                    const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
-                    const float dls[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const int qb = q0 + 8 * r4 + 4 * hi;     // rows tile_row(4 r4 .. 4 r4 + 3, hi) are four consecutive queries
+                    const float4 d4 = *(const float4*)(ndl_l + qb);
+                    const float4 l4 = *(const float4*)(lse_l + qb);
+                    dp[4 * r4] = d4.x; dp[4 * r4 + 1] = d4.y; dp[4 * r4 + 2] = d4.z; dp[4 * r4 + 3] = d4.w;
+                    nls[4 * r4] = l4.x; nls[4 * r4 + 1] = l4.y; nls[4 * r4 + 2] = l4.z; nls[4 * r4 + 3] = l4.w;
+                }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = r4 * 4 + e;
-                        // padded queries: combT = 0 but lse slot = 0 and Q = dO = 0 -> mask explicitly
-                        const float p = (k_ok && qb + e < N) ? fast_exp2(fmaf(s[r], sc, c[r]) - ls[e]) : 0.f;
-                        pd[r] = p;
-                        ds[r] = p * (dp[r] - dls[e]);
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int off = krow_off<HD>(q0 + j, ks * 2 + hi);
+                    bf16x8 qa = *(const bf16x8*)(Qs + off);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+                    bf16x8 ga = *(const bf16x8*)(Gs + off);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp, 0, 0, 0);
+                }
+                uint32_t pk[8], dsk[8];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    float p0 = fast_exp2(fmaf(s[r], sc, -nls[r])), p1 = fast_exp2(fmaf(s[r + 1], sc, -nls[r + 1]));
+                    float d0 = p0 * dp[r], d1 = p1 * dp[r + 1];
+                    if (qt == NT - 1) {                      // padded query rows of the last tile: their lse / delta slots were never
+                        const int qq = q0 + tile_row(r, hi);     // written (selects, not multiplies: the garbage may be inf / NaN)
+                        if (qq >= N) { p0 = 0.f; d0 = 0.f; }
+                        if (qq + 1 >= N) { p1 = 0.f; d1 = 0.f; }
                     }
+                    pk[r >> 1] = pack2(p0, p1);
+                    dsk[r >> 1] = pack2(d0, d1);
                 }
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
-                    bf16x8 pf = pack_frag(pd + 8 * sl), dsf = pack_frag(ds + 8 * sl);
-                    bf16x8 gt = tr_frag<HD>(Gv, q0 + 16 * sl, 0, lane);
-                    dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf, dv, 0, 0, 0);
-                    bf16x8 qt_ = tr_frag<HD>(Qv, q0 + 16 * sl, 0, lane);
-                    dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, dsf, dk, 0, 0, 0);
+                    Frag pf, df;
+                    pf.u = make_uint4(pk[4 * sl], pk[4 * sl + 1], pk[4 * sl + 2], pk[4 * sl + 3]);
+                    df.u = make_uint4(dsk[4 * sl], dsk[4 * sl + 1], dsk[4 * sl + 2], dsk[4 * sl + 3]);
+                    bf16x8 gt = tr_frag_k32(Gs, q0 + 16 * sl, lane);
+                    dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf.b, dv, 0, 0, 0);
+                    bf16x8 qt_ = tr_frag_k32(Qs, q0 + 16 * sl, lane);
+                    dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, df.b, dk, 0, 0, 0);
                 }
             }
             if (k_ok) {
@@ -543,27 +520,184 @@ __global__ __launch_bounds__(512) void win_dkv_p(AttnArgs a, int bsplit, const f
                 }
             }
         }
-        if (b + 1 < g.b1) stash(cur ^ 1);
+        dma_wait_all();
         __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
-// fragment-ordered (bias + shift mask + key padding) tables, exp2 domain (values multiplied by log2 e)
-//   comb [type][head][qt][kt][lane][r]: query = qt*32 + (lane&31), key = kt*32 + tile_row(r, lane>>5)
-//   combT[type][head][kt][qt][lane][r]: key   = kt*32 + (lane&31), query = qt*32 + tile_row(r, lane>>5)
+// relative-position-bias gradient: dtable[code(q) - code(k) + const, head] += sum over windows and batch of dS[q, k].
+// Workgroup = (head, window position, query half, batch slice); wave = (query strip qs of the half, key half kh): 4 key tiles,
+// 64 accumulators fed by one-hot MFMAs (dsa += E . dS: no VALU work), flushed once per workgroup through LDS float atomics.
+// LDS: [2][K 16 KB | V 16 KB | Q half 8 KB | dO half 8 KB | lse 1 KB | -delta 1 KB] + table + codes + token rows.
+// ------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(512) void win_dbias3(AttnArgs a, int bsplit, const float* ndelta_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WinGeo g;
+    const int qh = blockIdx.x & 1;
+    if (!win_geo(a, bsplit, blockIdx.x >> 1, g)) return;
+    constexpr int BUF = 32768 + 16384 + 2048;
+    float* dtbl = (float*)(smem + 2 * BUF);
+    int* kcode = (int*)(dtbl + a.tbl_rows);
+    int* srel_l = kcode + 256;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qs = wave & 3, kh = wave >> 2;
+    const int qt = qh * 4 + qs;
+    const int N = a.N, C = a.C, ld = 3 * C;
+    const float sc = a.d.scale * LOG2E;
+    for (int r = tid; r < a.tbl_rows; r += 512) dtbl[r] = 0.f;
+    if (tid < 256) {
+        const int i = tid;
+        kcode[i] = i < N ? (i / (a.d.cfg_ww * a.d.cfg_wh)) * a.cstride_d + ((i / a.d.cfg_ww) % a.d.cfg_wh) * a.cstride_h + (i % a.d.cfg_ww) : 0;
+        const int rel = a.d.tok_table[g.ws * 256 + i];
+        srel_l[i] = rel < 0 ? 0 : rel;
+    }
+    const int q = qt * 32 + j;
+    const bool q_ok = q < N;
+    const bool strip_on = qt < NT;                           // wave-uniform
+    constexpr int NK = 4;                                    // key tiles per key half: kh * 4 + i
+    const bf16_t* comb = (const bf16_t*)a.d.comb + ((long)(g.type * a.d.heads + g.head) * 64 + qt * 8 + kh * 4) * 1024 + lane * 8;
+    Frag cb[NK][2];
+#pragma unroll
+    for (int t = 0; t < NK; ++t) { cb[t][0].u = *(const uint4*)(comb + t * 1024); cb[t][1].u = *(const uint4*)(comb + t * 1024 + 512); }
+    const bf16x8 id0 = ident_frag(0, j, hi), id1 = ident_frag(1, j, hi);
+    // one-hot A fragments: E_sl[i][k-slot (hi, e)] = 1 iff i == 16 sl + 8 (e >> 2) + 4 hi + (e & 3)
+    bf16x8 onehot[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        float e8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) e8[e] = (j == 16 * sl + 8 * (e >> 2) + 4 * hi + (e & 3)) ? 1.f : 0.f;
+        onehot[sl] = pack_frag(e8);
+    }
+    f32x16 dsa[NK];
+#pragma unroll
+    for (int t = 0; t < NK; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsa[t][r] = 0.f;
+    __syncthreads();
+    unsigned offk[2], offs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) offk[i] = dma_off(srel_l, wave * 2 + i, lane, ld, C + g.head * HD);
+    // Q / dO strips of this query half: 4 strips x 2 pieces, wave w moves piece w of each operand
+    offs[0] = dma_off(srel_l, qh * 8 + wave, lane, ld, g.head * HD);
+    offs[1] = dma_off(srel_l, qh * 8 + wave, lane, C, g.head * HD);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const long lse_row = (long)g.ws * a.d.heads + g.head;
+    auto issue = [&](int b, int buf) {
+        const bf16_t* bq = a.qkv + (long)b * a.tps * ld;
+        const bf16_t* bg = a.dout + (long)b * a.tps * C;
+        const unsigned d0 = lds0 + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dma16(d0 + wave * 2048 + i * 1024, bq, offk[i]);
+            dma16(d0 + 16384 + wave * 2048 + i * 1024, bq, offk[i] + 2 * C);
+        }
+        dma16(d0 + 32768 + wave * 1024, bq, offs[0]);
+        dma16(d0 + 32768 + 8192 + wave * 1024, bg, offs[1]);
+        const long lo = ((long)b * a.nWs * a.d.heads + lse_row) * a.Npad;
+        if (wave == 0) dma16(d0 + 49152, a.lse + lo, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
+        if (wave == 1) dma16(d0 + 49152 + 1024, ndelta_in + lo, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
+    };
+    issue(g.b0, 0);
+    dma_wait_all();
+    __syncthreads();
+
+    for (int b = g.b0; b < g.b1; ++b) {
+        const int cur = (b - g.b0) & 1;
+        const char* Ks = smem + cur * BUF;
+        const char* Vs = Ks + 16384;
+        const char* Sq = Ks + 32768 + qs * 2048;            // K-type rows of the strip (row j of the strip at local row j)
+        const char* Sg = Sq + 8192;
+        const float* lse_l = (const float*)(Ks + 49152);
+        const float* ndl_l = lse_l + 256;
+        if (b + 1 < g.b1) issue(b + 1, cur ^ 1);
+        if (strip_on) {
+            bf16x8 qf[2], dof[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = krow_off<HD>(j, ks * 2 + hi);
+                qf[ks] = *(const bf16x8*)(Sq + off); dof[ks] = *(const bf16x8*)(Sg + off);
+            }
+            const float nl = q_ok ? -lse_l[q] : -INFINITY;
+            const float nd = q_ok ? ndl_l[q] : 0.f;
+            f32x16 ndl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ndl[r] = nd;
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int t = kh * 4 + i;
+                if (t >= NT) break;                          // wave-uniform
+                const f32x16 z = ZERO16;
+                f32x16 s, dp = ndl;
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[i][0].b, id0, z, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[i][1].b, id1, s, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int off = krow_off<HD>(t * 32 + j, ks * 2 + hi);
+                    bf16x8 kf = *(const bf16x8*)(Ks + off);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                    bf16x8 vf = *(const bf16x8*)(Vs + off);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+                }
+                uint32_t dk[8];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2)
+                    dk[r >> 1] = pack2(fast_exp2(fmaf(s[r], sc, nl)) * dp[r], fast_exp2(fmaf(s[r + 1], sc, nl)) * dp[r + 1]);
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    Frag df; df.u = make_uint4(dk[4 * sl], dk[4 * sl + 1], dk[4 * sl + 2], dk[4 * sl + 3]);
+                    dsa[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(onehot[sl], df.b, dsa[i], 0, 0, 0);
+                }
+            }
+        }
+        dma_wait_all();
+        __syncthreads();
+    }
+    // ---- flush: accumulators -> LDS table (index = code(q) - code(k) + const) -> one global atomic per table row ------------
+    if (strip_on && q_ok) {
+        const int qc = kcode[q] + a.tbl_const;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int t = kh * 4 + i;
+            if (t >= NT) break;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = t * 32 + tile_row(r, hi);
+                if (k < N) atomicAdd(&dtbl[qc - kcode[k]], dsa[i][r]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < a.tbl_rows; r += 512) {
+        const float v = dtbl[r];
+        if (v != 0.f) atomicAdd(a.dbias + (long)r * a.d.heads + g.head, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// (bias + shift mask + key padding) / scale tables as MFMA A-operand fragments (two 16-wide contraction slabs per 32x32 tile):
+//   comb [type][head][qt][kt][slab][lane][8]: A[i = key   kt*32 + (lane & 31)][k = query qt*32 + 16 slab + 8 (lane >> 5) + e]
+//   combT[type][head][kt][qt][slab][lane][8]: A[i = query qt*32 + (lane & 31)][k = key   kt*32 + 16 slab + 8 (lane >> 5) + e]
+// value(q, k) = (table[index(q, k), head] + (region(q) != region(k) ? -100 : 0)) / scale, -30000 / scale for padded keys
+// (video_swin.py:153-160), 0 for padded queries.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void build_bias_kernel(AttnArgs a, bf16_t* comb, bf16_t* combT) {
-    const long total = (long)a.d.n_types * a.d.heads * 64 * 64 * 16;
+    const long total = (long)a.d.n_types * a.d.heads * 64 * 2 * 64 * 8;
     const lav_attn_desc& d = a.d;
+    const float inv_scale = 1.0f / d.scale;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int r = idx & 15, lane = (idx >> 4) & 63, t1 = (idx >> 10) & 7, t0 = (idx >> 13) & 7;
+        const int e = idx & 7, lane = (idx >> 3) & 63, slab = (idx >> 9) & 1, t1 = (idx >> 10) & 7, t0 = (idx >> 13) & 7;
         const int head = (idx >> 16) % d.heads, type = (idx >> 16) / d.heads;
         const int jj = lane & 31, hi = lane >> 5;
+        const int row = jj, col = 16 * slab + 8 * hi + e;   // (row i, contraction index k) inside the 32 x 32 tile
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
-            const int q = which == 0 ? t0 * 32 + jj : t1 * 32 + tile_row(r, hi);
-            const int k = which == 0 ? t1 * 32 + tile_row(r, hi) : t0 * 32 + jj;
+            // comb: t0 = query tile, t1 = key tile, row = key, col = query;  combT: t0 = key tile, t1 = query tile, row = query, col = key
+            const int q = which == 0 ? t0 * 32 + col : t1 * 32 + row;
+            const int k = which == 0 ? t1 * 32 + row : t0 * 32 + col;
             float v;
             if (k >= a.N) v = -30000.f;
             else if (q >= a.N) v = 0.f;
@@ -575,7 +709,7 @@ __global__ __launch_bounds__(256) void build_bias_kernel(AttnArgs a, bf16_t* com
                 v = d.bias_table[(long)bi * d.heads + head];
                 if (d.type_region[type * 256 + q] != d.type_region[type * 256 + k]) v += -100.0f;
             }
-            (which == 0 ? comb : combT)[idx] = f2bf(v * LOG2E);
+            (which == 0 ? comb : combT)[idx] = f2bf(v * inv_scale);
         }
     }
 }
@@ -584,14 +718,14 @@ extern "C" int lav_attention_build_bias(void* stream, const lav_attn_desc* d) {
     AttnArgs a; int problems = 0;
     if (int rc = attn_setup(d, a, problems)) return rc;
     LAV_REQUIRE(d->mode == 0 && d->comb && d->combT, "lav_attention_build_bias: window mode with comb/combT buffers required");
-    long total = (long)d->n_types * d->heads * 64 * 64 * 16;
+    long total = (long)d->n_types * d->heads * 64 * 2 * 64 * 8;
     int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(build_bias_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, (bf16_t*)d->comb, (bf16_t*)d->combT);
     return lav_check_launch("lav_attention_build_bias");
 }
 
-static int pick_bsplit(const AttnArgs& a) {
-    const int base = a.d.heads * a.nWs;
+static int pick_bsplit(const AttnArgs& a, int per_pair = 1) {
+    const int base = a.d.heads * a.nWs * per_pair;
     int bs = (256 + base - 1) / base;
     if (bs > a.d.B) bs = a.d.B;
     if (bs < 1) bs = 1;
@@ -604,32 +738,42 @@ static void big_lds(Kn k, size_t bytes) {
     (void)hipGetLastError();
 }
 
+#define NT_SWITCH(nt, MACRO)                                                                         \
+    switch (nt) { case 8: MACRO(8) break; case 7: MACRO(7) break; case 6: MACRO(6) break; case 5: MACRO(5) break; \
+                  case 4: MACRO(4) break; case 3: MACRO(3) break; case 2: MACRO(2) break; default: MACRO(1) }
+
 int win_persistent_fwd(void* stream, const AttnArgs& a) {
     const int bs = pick_bsplit(a);
-    const size_t lds = 2 * 32768;
-    hipLaunchKernelGGL(win_fwd_p, dim3(a.d.heads * a.nWs * bs), dim3(512), lds, (hipStream_t)stream, a, bs);
+    const size_t lds = 2 * 49152 + 1024;
+    const dim3 grid(a.d.heads * a.nWs * bs);
+#define FWD3_(NT) { big_lds(win_fwd3<NT>, lds); hipLaunchKernelGGL(win_fwd3<NT>, grid, dim3(512), lds, (hipStream_t)stream, a, bs); }
+    NT_SWITCH((a.N + 31) / 32, FWD3_)
+#undef FWD3_
     return lav_check_launch("lav_attention_fwd(window, persistent)");
 }
 
-// LAV_WIN_BWD_FUSED=1 selects the single-kernel backward of attention_win_bwd.hip (measured slower on every Swin-B stage:
-// 10.9 vs 8.9 ms per step); the default is the two-pass form below (dQ + bias gradient, then dK / dV)
-static const bool lav_win_bwd_fused = getenv("LAV_WIN_BWD_FUSED") ? atoi(getenv("LAV_WIN_BWD_FUSED")) != 0 : false;
+// needs lse (forward) and -delta (written by the dQ pass of win_persistent_bwd on the same problem)
+int win_persistent_dbias(void* stream, const AttnArgs& a, const float* ndelta) {
+    const int bs = pick_bsplit(a, 2);
+    const dim3 grid(a.d.heads * a.nWs * bs * 2);
+    const size_t lds = 2 * (32768 + 16384 + 2048) + (size_t)a.tbl_rows * 4 + 2048;
+#define DB3_(NT) { big_lds(win_dbias3<NT>, lds); hipLaunchKernelGGL(win_dbias3<NT>, grid, dim3(512), lds, (hipStream_t)stream, a, bs, ndelta); }
+    NT_SWITCH((a.N + 31) / 32, DB3_)
+#undef DB3_
+    return lav_check_launch("lav_attention_bwd_bias(window, persistent)");
+}
 
-int win_persistent_bwd(void* stream, const AttnArgs& a, float* delta) {
+int win_persistent_bwd(void* stream, const AttnArgs& a, float* ndelta) {
     const int bs = pick_bsplit(a);
-    if (lav_win_bwd_fused) return win_fused_bwd(stream, a, bs);
-    const size_t lds1 = 2 * 49152 + 2048 + (size_t)a.tbl_rows * 16;
-    // with the bias-table gradient the resident dS sums need the 512-register budget of one wave per SIMD (the 8-wave
-    // variant spills in its inner loop: 375 vs 309 us on the stage-2 shape); without it two waves per SIMD win (202 vs 230 us)
-    if (a.dbias) {
-        big_lds((win_dq_p<true, 4>), lds1);
-        hipLaunchKernelGGL((win_dq_p<true, 4>), dim3(a.d.heads * a.nWs * bs), dim3(256), lds1, (hipStream_t)stream, a, bs, delta);
-    } else {
-        big_lds((win_dq_p<false, 8>), lds1);
-        hipLaunchKernelGGL((win_dq_p<false, 8>), dim3(a.d.heads * a.nWs * bs), dim3(512), lds1, (hipStream_t)stream, a, bs, delta);
-    }
-    const size_t lds2 = 2 * (65536 + 2048);
-    big_lds(win_dkv_p, lds2);
-    hipLaunchKernelGGL(win_dkv_p, dim3(a.d.heads * a.nWs * bs), dim3(512), lds2, (hipStream_t)stream, a, bs, (const float*)delta);
+    const dim3 grid(a.d.heads * a.nWs * bs);
+    const size_t lds1 = 2 * (32768 + 1024) + 8 * 6144 + 1024;
+    const size_t lds2 = 2 * (32768 + 2048) + 8 * 4096 + 1024;
+#define DQ3_(NT) { big_lds(win_dq3<NT>, lds1); hipLaunchKernelGGL(win_dq3<NT>, grid, dim3(512), lds1, (hipStream_t)stream, a, bs, ndelta); }
+    NT_SWITCH((a.N + 31) / 32, DQ3_)
+#undef DQ3_
+#define DKV3_(NT) { big_lds(win_dkv3<NT>, lds2); hipLaunchKernelGGL(win_dkv3<NT>, grid, dim3(512), lds2, (hipStream_t)stream, a, bs, (const float*)ndelta); }
+    NT_SWITCH((a.N + 31) / 32, DKV3_)
+#undef DKV3_
+    if (a.dbias) return win_persistent_dbias(stream, a, ndelta);
     return lav_check_launch("lav_attention_bwd(window, persistent)");
 }

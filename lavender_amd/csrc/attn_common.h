@@ -27,8 +27,8 @@ struct AttnArgs {
 
 int attn_setup(const lav_attn_desc* d, AttnArgs& a, int& problems);
 int win_persistent_fwd(void* stream, const AttnArgs& a);
-int win_persistent_bwd(void* stream, const AttnArgs& a, float* delta);
-int win_fused_bwd(void* stream, const AttnArgs& a, int bsplit);
+int win_persistent_bwd(void* stream, const AttnArgs& a, float* ndelta);     // dQ, dK, dV (+ bias gradient when a.dbias)
+int win_persistent_dbias(void* stream, const AttnArgs& a, const float* ndelta);
 
 // fast window path: token rows from the precomputed per-window table instead of div/mod chains
 __device__ __forceinline__ int tok_row(const AttnArgs& a, int win, int i) {

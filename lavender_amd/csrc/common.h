@@ -35,11 +35,15 @@ __device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, Na
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
-// two floats -> packed bf16 pair (lo = a, hi = b), round-to-nearest-even in ONE VALU op (gfx950 v_cvt_pk_bf16_f32)
+// two floats -> packed bf16 pair (lo = a, hi = b), round-to-nearest-even in ONE VALU op (gfx950 v_cvt_pk_bf16_f32).
+// Through the vector conversion, NOT inline asm: hipcc selects the same instruction and -- unlike for an asm statement --
+// inserts the wait states an MFMA needs before it reads a just-converted operand (round 3: the asm form fed stale registers
+// to the P^T.dO MFMAs of the dK / dV window kernel whenever the scheduler put them back to back).
+typedef __attribute__((ext_vector_type(2))) __bf16 lav_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float lav_f32x2;
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    const lav_f32x2 f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, lav_bf16x2));
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // raw v_exp_f32
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {

@@ -224,7 +224,18 @@ class SwinBlockFn(torch.autograd.Function):
             # padded geometry: zero output-gradient rows for the padded tokens; their dK / dV (they ARE attended to) reach the
             # qkv bias through the row sum over all Ma rows, the weight sees nothing from them (their y1 rows are zero)
             d_ao, ao = K.gather_rows(d_ao, pad[2], Ma, C), ao_p
-        att.bwd(qkv, ao, d_ao, lse, dqkv, G(a.relative_position_bias_table))
+        if att.split_bias_grad and _DW_SIDE:
+            # the relative-position-bias gradient is a parameter gradient: its kernel (it re-derives dS from qkv, dO, lse and
+            # the -delta the dQ pass leaves behind the lse) runs on the weight-gradient stream, off the dy -> dx chain
+            att.bwd(qkv, ao, d_ao, lse, dqkv, None)
+            side = dw_stream(qkv.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                att.bwd_bias(qkv, d_ao, lse, G(a.relative_position_bias_table))
+            for t in (qkv, d_ao, lse):
+                t.record_stream(side)
+        else:
+            att.bwd(qkv, ao, d_ao, lse, dqkv, G(a.relative_position_bias_table))
         dw_gemm(dqkv, y1, 3 * C, C, Ma, out=G(a.qkv.weight), accumulate=True, splits=K.splits_for(3 * C, C, Ma),
                rowsum_a=G(a.qkv.bias))
         d_y1 = K.gemm(0, dqkv, W16T(a.qkv.weight), Ma, C, 3 * C)

@@ -249,6 +249,14 @@ class Attn:
         L.check(L.lib.lav_attention_bwd(_s(), C.byref(self.d), _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(dbias)),
                 "lav_attention_bwd")
 
+    @property
+    def split_bias_grad(self):
+        """True when the bias-table gradient can run as its own launch (bwd(..., dbias=None) then bwd_bias on any stream)."""
+        return self.d.mode == 0 and bool(self.d.comb)
+
+    def bwd_bias(self, qkv, dout, lse, dbias):
+        L.check(L.lib.lav_attention_bwd_bias(_s(), C.byref(self.d), _p(qkv), _p(dout), _p(lse), _p(dbias)), "lav_attention_bwd_bias")
+
 
 def patch_im2col(img, B, T, H, W, frame_major):
     out = torch.empty((B * T * (H // 4) * (W // 4), 96), dtype=bf16, device=img.device)

@@ -361,6 +361,14 @@ def test_window_attention_fwd_bwd(case):
     close(dqkv, qr.grad, atol=4e-2, rtol=4e-2, what=f"window dqkv {case}")
     rel = (dtab.cpu() - tr.grad).norm() / tr.grad.norm()
     assert rel < 2e-2, f"bias-table gradient rel err {rel.item():.3g}"
+    if att.split_bias_grad:
+        # the engine's form: dQ / dK / dV on the main stream, the table gradient as its own launch (lav_attention_bwd_bias)
+        dqkv2, dtab2 = torch.empty_like(qkv), torch.zeros_like(table)
+        att.bwd(qkv, out, dout, lse, dqkv2, None)
+        att.bwd_bias(qkv, dout, lse, dtab2)
+        assert torch.equal(dqkv2, dqkv)
+        rel2 = (dtab2.cpu() - tr.grad).norm() / tr.grad.norm()
+        assert rel2 < 2e-2, f"bias-table gradient (split launch) rel err {rel2.item():.3g}"
 
 
 def _seq_ref(qkv, mask, n, L, heads):
