@@ -704,6 +704,7 @@ extern "C" int lav_attention_fwd(void* stream, const lav_attn_desc* d, const voi
     LAV_REQUIRE(qkv && out, "lav_attention_fwd: null pointer");
     a.qkv = (const bf16_t*)qkv; a.o_w = (bf16_t*)out; a.lse = lse;
     if (d->mode == 0 && d->comb) return win_persistent_fwd(stream, a);
+    if (seq3_supported(a)) return seq3_fwd(stream, a, problems);
     hipStream_t s = (hipStream_t)stream;
     const int KL = d->mode == 0 ? WIN_KL : SEQ_KL_FWD;
     const int qgroups = (a.nqt + 3) / 4;
@@ -737,6 +738,7 @@ extern "C" int lav_attention_bwd(void* stream, const lav_attn_desc* d, const voi
     a.dqkv = (bf16_t*)dqkv; a.dbias = dbias_table;
     float* delta = (float*)lse + (size_t)problems * d->heads * a.Npad;
     if (d->mode == 0 && d->comb) return win_persistent_bwd(stream, a, delta);
+    if (seq3_supported(a)) return seq3_bwd(stream, a, problems, delta);
     hipStream_t s = (hipStream_t)stream;
     const int qgroups = (a.nqt + 3) / 4;
     if (d->mode == 0) {

@@ -1,0 +1,483 @@
+// Fusion-encoder (BERT) self-attention for gfx950, sequences of up to 288 tokens (the pre-training / retrieval / QA shapes:
+// L = 250 video + 26..32 text tokens), head_dim 64, key mask, counter-hash dropout on P, optional seq2seq mask.
+// Round-3 kernels, same rules as attention_win.hip:
+//   * K and V (forward, dQ pass) or Q and dO (dK / dV pass) of a (sequence, head) problem arrive by global_load_lds into ONE
+//     slot-swizzled LDS image each (128-byte rows = full cache lines of the token-major qkv tensor) that serves both the
+//     ds_read_b128 fragment reads and the transposing ds_read_b64_tr_b16 reads; the image is waited for once per problem.
+//     Nothing is staged through registers, no global load is consumed while a DMA is in flight.
+//   * the additive key mask enters the score tile as the C operand of its first MFMA (forward / dQ) or as a per-wave constant
+//     (dK / dV); delta enters dP the same way; the softmax row sum is one more MFMA against a one-row ones fragment.
+//     VALU per score element: fma + exp (+ the dropout hash) + 1/2 max3 + cvt_pk.
+//   * 256-thread workgroups, two per CU (74-76 KB of LDS each): while one waits for its next problem's image the other computes.
+//     A workgroup walks problems blockIdx.x, blockIdx.x + gridDim.x, ...; its four waves take the 32-row tiles round-robin.
+//   * the S tile of step t+1 is issued before the softmax of step t (matrix pipe under the VALU chain of the same wave).
+// Longer sequences (the 757-token Swin-L-384 shape) stay on the generic kernels of attention.hip.
+#include "attn_common.h"
+
+#define LOG2E 1.4426950408889634f
+#define HD 64
+#define SEQ3_ROWS 288                                      // LDS image rows
+#define SEQ3_IMG (SEQ3_ROWS * 128)
+
+__device__ __forceinline__ void sdma16(unsigned lds_dst, const void* sbase, unsigned voff) {
+    unsigned keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void sdma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+union SFrag { uint4 u; bf16x8 b; };
+#define SZERO16 {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
+
+__device__ __forceinline__ float smax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// transposing A-operand read (32 d-values d0 .. d0 + 31 x 16 rows) from a K-type (slot-swizzled) 128-byte-row image
+__device__ __forceinline__ bf16x8 tr_frag_k64(const char* tile, int row_base, int d0, int lane) {
+    const int i = lane & 15, dhalf = (lane >> 4) & 1, hi = lane >> 5;
+    const int r = i >> 2, c = i & 3;
+    const int dcol = d0 + 16 * dhalf + 4 * c;
+    const int slot = dcol >> 3, sub = (dcol & 7) * 2;
+    const int row0 = row_base + 4 * hi + r;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + krow_off<64>(row0, slot) + sub));
+    s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + krow_off<64>(row0 + 8, slot) + sub));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi4;
+    return u.v;
+}
+
+// DMA of one operand image: rows [0, nrow8 * 8) of a (sequence, head) slice, 1-KB pieces of 8 rows x 128 B; wave w moves pieces
+// w, w + 4, ...  Rows past the sequence end re-read its last row (never used: masked keys / padded queries).
+__device__ __forceinline__ void seq_dma_image(unsigned lds_img, const bf16_t* base, long ld, int L, int npiece, int wave, int lane) {
+    for (int t = wave; t < npiece; t += 4) {
+        const int row = min(t * 8 + (lane >> 3), L - 1);
+        const int prow = t * 8 + (lane >> 3);
+        const int lslot = (lane & 7) ^ ((prow >> 1) & 7);
+        sdma16(lds_img + t * 1024, base, (unsigned)((row * ld + lslot * 8) * 2));
+    }
+}
+
+// counter-hash dropout factor pair for two adjacent keys (one hash per key pair, 16-bit halves): see attention.hip
+__device__ __forceinline__ void drop_pair(uint32_t seed, uint32_t idx, uint32_t thresh16, float inv, float& m0, float& m1) {
+    const uint32_t h = lav_hash32(seed, idx);
+    m0 = (h & 0xffffu) >= thresh16 ? inv : 0.f;
+    m1 = (h >> 16) >= thresh16 ? inv : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward.  LDS: K image | V image | additive key mask (fp32, 0 / -inf; -inf past the sequence end).
+// ------------------------------------------------------------------------------------------------------
+template <bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(256, 2) void seq_fwd3(AttnArgs a, int nprob) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + SEQ3_IMG;
+    float* kadd = (float*)(smem + 2 * SEQ3_IMG);
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, C = a.C, ld = 3 * C;
+    const int nt = a.nqt, npiece = nt * 4;
+    const float sc = a.d.scale * LOG2E;
+    const float inv_keep = DROP ? 1.f / (1.f - a.d.dropout_p) : 1.f;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    bf16x8 ones0;
+    {
+        float e8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) e8[e] = j == 0 ? 1.f : 0.f;
+        ones0 = pack_frag(e8);
+    }
+    for (int p = blockIdx.x; p < nprob; p += gridDim.x) {
+        const int prob = p / a.d.heads, head = p - prob * a.d.heads;
+        const bf16_t* qbase = a.qkv + (long)prob * N * ld + head * HD;
+        __syncthreads();                                     // every wave is done with the previous problem's images
+        seq_dma_image(lds0, qbase + C, ld, N, npiece, wave, lane);
+        seq_dma_image(lds0 + SEQ3_IMG, qbase + 2 * C, ld, N, npiece, wave, lane);
+        for (int k = tid; k < nt * 32; k += 256)
+            kadd[k] = (k >= N || (a.d.key_mask && a.d.key_mask[(long)prob * N + k] == 0)) ? -INFINITY : 0.f;
+        sdma_wait_all();
+        __syncthreads();
+
+        for (int qt = wave; qt < nt; qt += 4) {
+            const int q = qt * 32 + j;
+            const bool q_ok = q < N;
+            const long qrow = (long)min(q, N - 1);
+            bf16x8 qf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { SFrag f; f.u = *(const uint4*)(qbase + qrow * ld + ks * 16 + 8 * hi); qf[ks] = f.b; }
+            f32x16 o0 = SZERO16, o1 = SZERO16, lacc = SZERO16;
+            float m_run = -INFINITY;
+            const uint32_t drow = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)q) * (uint32_t)a.NH;
+            f32x16 sa, sb;
+            auto qk = [&](int t, f32x16& s) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {             // C operand = additive mask of the tile's keys (rows of S^T)
+                    const float4 m4 = *(const float4*)(kadd + t * 32 + 8 * r4 + 4 * hi);
+                    s[4 * r4] = m4.x; s[4 * r4 + 1] = m4.y; s[4 * r4 + 2] = m4.z; s[4 * r4 + 3] = m4.w;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    bf16x8 kf = *(const bf16x8*)(Ks + krow_off<HD>(t * 32 + j, ks * 2 + hi));
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                }
+            };
+            auto soft = [&](int t, f32x16& s) {
+                if (CAUSAL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kk = t * 32 + tile_row(r, hi);
+                        if (kk >= a.d.causal_from && (q < a.d.causal_from || kk > q)) s[r] = -INFINITY;
+                    }
+                }
+                float mx = smax3(s[0], s[1], s[2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) mx = smax3(mx, s[r], s[r + 1]);
+                mx = fmaxf(mx, s[15]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+                if (__any(mx > m_run)) {
+                    const float m_new = fmaxf(m_run, mx);
+                    const float alpha = fast_exp2(m_run - m_new);   // m_run = -inf -> 0; a fully masked prefix keeps m = -inf
+                    lacc[0] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                    m_run = m_new;
+                }
+                const float nm = m_run == -INFINITY ? 0.f : -m_run;
+                uint32_t pk[8], pd[8];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const int r = r4 * 4 + 2 * e2;
+                        const float p0 = fast_exp2(fmaf(s[r], sc, nm)), p1 = fast_exp2(fmaf(s[r + 1], sc, nm));
+                        pk[r >> 1] = pack2(p0, p1);
+                        if (DROP) {
+                            float m0, m1;
+                            drop_pair(a.d.seed, drow + (uint32_t)((t * 32 + 4 * hi) >> 1) + (uint32_t)(4 * r4 + e2), a.thresh16, inv_keep, m0, m1);
+                            pd[r >> 1] = pack2(p0 * m0, p1 * m1);
+                        }
+                    }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    SFrag pf, pq;
+                    pf.u = make_uint4(pk[4 * sl], pk[4 * sl + 1], pk[4 * sl + 2], pk[4 * sl + 3]);
+                    if (DROP) pq.u = make_uint4(pd[4 * sl], pd[4 * sl + 1], pd[4 * sl + 2], pd[4 * sl + 3]); else pq.u = pf.u;
+                    lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones0, pf.b, lacc, 0, 0, 0);      // normaliser: the un-dropped P
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Vs, t * 32 + 16 * sl, 0, lane), pq.b, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Vs, t * 32 + 16 * sl, 32, lane), pq.b, o1, 0, 0, 0);
+                }
+            };
+            qk(0, sa);
+#pragma unroll 1
+            for (int t = 0; t < nt; t += 2) {
+                if (t + 1 < nt) qk(t + 1, sb);
+                soft(t, sa);
+                if (t + 1 < nt) {
+                    if (t + 2 < nt) qk(t + 2, sa);
+                    soft(t + 1, sb);
+                }
+            }
+            const float l_tot = __shfl(lacc[0], j, 64);
+            const float inv_l = l_tot > 0.f ? 1.f / l_tot : 0.f;
+            if (q_ok) {
+                bf16_t* op = a.o_w + ((long)prob * N + q) * C + head * HD;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    uint2 w;
+                    w.x = pack2(o0[r4 * 4 + 0] * inv_l, o0[r4 * 4 + 1] * inv_l);
+                    w.y = pack2(o0[r4 * 4 + 2] * inv_l, o0[r4 * 4 + 3] * inv_l);
+                    *(uint2*)(op + 8 * r4 + 4 * hi) = w;
+                    w.x = pack2(o1[r4 * 4 + 0] * inv_l, o1[r4 * 4 + 1] * inv_l);
+                    w.y = pack2(o1[r4 * 4 + 2] * inv_l, o1[r4 * 4 + 3] * inv_l);
+                    *(uint2*)(op + 32 + 8 * r4 + 4 * hi) = w;
+                }
+                if (a.lse && hi == 0) a.lse[(long)p * a.Npad + q] = m_run + log2f(l_tot);   // log2 domain
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward pass 1: dQ and delta[q] = sum_d dO[q,d] O[q,d] (stored as +delta behind the lse, as the generic kernels do).
+// LDS: K image | V image | additive key mask.
+// ------------------------------------------------------------------------------------------------------
+template <bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(256, 2) void seq_dq3(AttnArgs a, int nprob, float* delta_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + SEQ3_IMG;
+    float* kadd = (float*)(smem + 2 * SEQ3_IMG);
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, C = a.C, ld = 3 * C;
+    const int nt = a.nqt, npiece = nt * 4;
+    const float sc = a.d.scale * LOG2E;
+    const float inv_keep = DROP ? 1.f / (1.f - a.d.dropout_p) : 1.f;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    for (int p = blockIdx.x; p < nprob; p += gridDim.x) {
+        const int prob = p / a.d.heads, head = p - prob * a.d.heads;
+        const bf16_t* qbase = a.qkv + (long)prob * N * ld + head * HD;
+        __syncthreads();
+        seq_dma_image(lds0, qbase + C, ld, N, npiece, wave, lane);
+        seq_dma_image(lds0 + SEQ3_IMG, qbase + 2 * C, ld, N, npiece, wave, lane);
+        for (int k = tid; k < nt * 32; k += 256)
+            kadd[k] = (k >= N || (a.d.key_mask && a.d.key_mask[(long)prob * N + k] == 0)) ? -INFINITY : 0.f;
+        sdma_wait_all();
+        __syncthreads();
+
+        for (int qt = wave; qt < nt; qt += 4) {
+            const int q = qt * 32 + j;
+            const bool q_ok = q < N;
+            const long qrow = (long)prob * N + min(q, N - 1);
+            bf16x8 qf[4], dof[4];
+            float dl = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                SFrag fq, fg, fo;
+                fq.u = *(const uint4*)(a.qkv + qrow * ld + head * HD + ks * 16 + 8 * hi);
+                fg.u = *(const uint4*)(a.dout + qrow * C + head * HD + ks * 16 + 8 * hi);
+                fo.u = *(const uint4*)(a.out + qrow * C + head * HD + ks * 16 + 8 * hi);
+                qf[ks] = fq.b; dof[ks] = fg.b;
+                float gf[8], of[8];
+                unpack8(fg.u, gf); unpack8(fo.u, of);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl = fmaf(gf[e], of[e], dl);
+            }
+            dl += __shfl_xor(dl, 32, 64);
+            const float nl = q_ok ? -a.lse[(long)p * a.Npad + q] : -INFINITY;   // padded query: P = 0
+            if (q_ok && hi == 0) delta_out[(long)p * a.Npad + q] = dl;
+            const float ndl = -dl;
+            const uint32_t drow = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)q) * (uint32_t)a.NH;
+            f32x16 dq0 = SZERO16, dq1 = SZERO16;
+            f32x16 sa, pa;
+            auto front = [&](int t, f32x16& s, f32x16& dp) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 m4 = *(const float4*)(kadd + t * 32 + 8 * r4 + 4 * hi);
+                    s[4 * r4] = m4.x; s[4 * r4 + 1] = m4.y; s[4 * r4 + 2] = m4.z; s[4 * r4 + 3] = m4.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[r] = DROP ? 0.f : ndl;     // without dropout delta rides in as the C operand
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int off = krow_off<HD>(t * 32 + j, ks * 2 + hi);
+                    bf16x8 kf = *(const bf16x8*)(Ks + off);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                    bf16x8 vf = *(const bf16x8*)(Vs + off);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+                }
+            };
+            auto back = [&](int t, const f32x16& s, const f32x16& dp) {
+                uint32_t dk[8];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const int r = r4 * 4 + 2 * e2;
+                        float p0 = fast_exp2(fmaf(s[r], sc, nl)), p1 = fast_exp2(fmaf(s[r + 1], sc, nl));
+                        if (CAUSAL) {
+                            const int kk = t * 32 + 8 * r4 + 4 * hi + 2 * e2;
+                            if (kk >= a.d.causal_from && (q < a.d.causal_from || kk > q)) p0 = 0.f;
+                            if (kk + 1 >= a.d.causal_from && (q < a.d.causal_from || kk + 1 > q)) p1 = 0.f;
+                        }
+                        if (DROP) {
+                            float m0, m1;
+                            drop_pair(a.d.seed, drow + (uint32_t)((t * 32 + 4 * hi) >> 1) + (uint32_t)(4 * r4 + e2), a.thresh16, inv_keep, m0, m1);
+                            dk[r >> 1] = pack2(p0 * fmaf(dp[r], m0, ndl), p1 * fmaf(dp[r + 1], m1, ndl));
+                        } else {
+                            dk[r >> 1] = pack2(p0 * dp[r], p1 * dp[r + 1]);
+                        }
+                    }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    SFrag df; df.u = make_uint4(dk[4 * sl], dk[4 * sl + 1], dk[4 * sl + 2], dk[4 * sl + 3]);
+                    dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Ks, t * 32 + 16 * sl, 0, lane), df.b, dq0, 0, 0, 0);
+                    dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Ks, t * 32 + 16 * sl, 32, lane), df.b, dq1, 0, 0, 0);
+                }
+            };
+            // not software-pipelined (the second S / dP pair costs 32 registers and spills): the other workgroup of the CU covers
+#pragma unroll 1
+            for (int t = 0; t < nt; ++t) {
+                front(t, sa, pa);
+                back(t, sa, pa);
+            }
+            if (q_ok) {
+                bf16_t* op = a.dqkv + qrow * ld + head * HD;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    uint2 w;
+                    w.x = pack2(dq0[r4 * 4 + 0] * a.d.scale, dq0[r4 * 4 + 1] * a.d.scale);
+                    w.y = pack2(dq0[r4 * 4 + 2] * a.d.scale, dq0[r4 * 4 + 3] * a.d.scale);
+                    *(uint2*)(op + 8 * r4 + 4 * hi) = w;
+                    w.x = pack2(dq1[r4 * 4 + 0] * a.d.scale, dq1[r4 * 4 + 1] * a.d.scale);
+                    w.y = pack2(dq1[r4 * 4 + 2] * a.d.scale, dq1[r4 * 4 + 3] * a.d.scale);
+                    *(uint2*)(op + 32 + 8 * r4 + 4 * hi) = w;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward pass 2: dK, dV.  Wave owns 32-key tiles, loops over the queries.  LDS: Q image | dO image | lse (+inf for padded
+// queries) | delta.
+// ------------------------------------------------------------------------------------------------------
+template <bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(256, 2) void seq_dkv3(AttnArgs a, int nprob, const float* delta_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* Gs = smem + SEQ3_IMG;
+    float* qlse = (float*)(smem + 2 * SEQ3_IMG);
+    float* qdl = qlse + SEQ3_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, C = a.C, ld = 3 * C;
+    const int nt = a.nqt, npiece = nt * 4;
+    const float sc = a.d.scale * LOG2E;
+    const float inv_keep = DROP ? 1.f / (1.f - a.d.dropout_p) : 1.f;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    for (int p = blockIdx.x; p < nprob; p += gridDim.x) {
+        const int prob = p / a.d.heads, head = p - prob * a.d.heads;
+        const bf16_t* qbase = a.qkv + (long)prob * N * ld + head * HD;
+        __syncthreads();
+        seq_dma_image(lds0, qbase, ld, N, npiece, wave, lane);
+        seq_dma_image(lds0 + SEQ3_IMG, a.dout + (long)prob * N * C + head * HD, C, N, npiece, wave, lane);
+        for (int k = tid; k < nt * 32; k += 256) {
+            qlse[k] = k < N ? a.lse[(long)p * a.Npad + k] : INFINITY;     // padded query rows: P = exp2(v - inf) = 0
+            qdl[k] = k < N ? delta_in[(long)p * a.Npad + k] : 0.f;
+        }
+        sdma_wait_all();
+        __syncthreads();
+
+        for (int kt = wave; kt < nt; kt += 4) {
+            const int key = kt * 32 + j;
+            const bool k_ok = key < N;
+            const long krow = (long)prob * N + min(key, N - 1);
+            const float k_add = (!k_ok || (a.d.key_mask && a.d.key_mask[(long)prob * N + min(key, N - 1)] == 0)) ? -INFINITY : 0.f;
+            bf16x8 kf[4], vf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                SFrag fk, fv;
+                fk.u = *(const uint4*)(a.qkv + krow * ld + C + head * HD + ks * 16 + 8 * hi);
+                fv.u = *(const uint4*)(a.qkv + krow * ld + 2 * C + head * HD + ks * 16 + 8 * hi);
+                kf[ks] = fk.b; vf[ks] = fv.b;
+            }
+            f32x16 kadd16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kadd16[r] = k_add;
+            f32x16 dk0 = SZERO16, dk1 = SZERO16, dv0 = SZERO16, dv1 = SZERO16;
+            const uint32_t dcol = (uint32_t)(prob * a.d.heads + head) * (uint32_t)N;
+            const uint32_t sh = (uint32_t)(key & 1) * 16u;
+#pragma unroll 1
+            for (int qt = 0; qt < nt; ++qt) {
+                const int q0 = qt * 32;
+                f32x16 s = kadd16, dp = SZERO16;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int off = krow_off<HD>(q0 + j, ks * 2 + hi);
+                    bf16x8 qa = *(const bf16x8*)(Qs + off);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+                    bf16x8 ga = *(const bf16x8*)(Gs + off);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp, 0, 0, 0);
+                }
+                uint32_t pk[8], dsk[8];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int qb = q0 + 8 * r4 + 4 * hi;
+                    const float4 l4 = *(const float4*)(qlse + qb);
+                    const float4 d4 = *(const float4*)(qdl + qb);
+                    const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+                    const float dls[4] = {d4.x, d4.y, d4.z, d4.w};
+                    float pv[4], dsv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = r4 * 4 + e;
+                        float pe = fast_exp2(fmaf(s[r], sc, -ls[e]));
+                        if (CAUSAL) {
+                            const int qq = qb + e;
+                            if (key >= a.d.causal_from && (qq < a.d.causal_from || key > qq)) pe = 0.f;
+                        }
+                        float m = 1.f;
+                        if (DROP) {
+                            const uint32_t h = lav_hash32(a.d.seed, (dcol + (uint32_t)(qb + e)) * (uint32_t)a.NH + (uint32_t)(key >> 1));
+                            m = ((h >> sh) & 0xffffu) >= a.thresh16 ? inv_keep : 0.f;
+                        }
+                        pv[e] = DROP ? pe * m : pe;
+                        dsv[e] = pe * (DROP ? fmaf(dp[r], m, -dls[e]) : dp[r] - dls[e]);
+                    }
+                    pk[2 * r4] = pack2(pv[0], pv[1]); pk[2 * r4 + 1] = pack2(pv[2], pv[3]);
+                    dsk[2 * r4] = pack2(dsv[0], dsv[1]); dsk[2 * r4 + 1] = pack2(dsv[2], dsv[3]);
+                }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    SFrag pf, df;
+                    pf.u = make_uint4(pk[4 * sl], pk[4 * sl + 1], pk[4 * sl + 2], pk[4 * sl + 3]);
+                    df.u = make_uint4(dsk[4 * sl], dsk[4 * sl + 1], dsk[4 * sl + 2], dsk[4 * sl + 3]);
+                    dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Gs, q0 + 16 * sl, 0, lane), pf.b, dv0, 0, 0, 0);
+                    dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Gs, q0 + 16 * sl, 32, lane), pf.b, dv1, 0, 0, 0);
+                    dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Qs, q0 + 16 * sl, 0, lane), df.b, dk0, 0, 0, 0);
+                    dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Qs, q0 + 16 * sl, 32, lane), df.b, dk1, 0, 0, 0);
+                }
+            }
+            if (k_ok) {
+                bf16_t* op = a.dqkv + krow * ld + head * HD;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = 8 * r4 + 4 * hi;
+                    uint2 w;
+                    w.x = pack2(dk0[r4 * 4 + 0] * a.d.scale, dk0[r4 * 4 + 1] * a.d.scale);
+                    w.y = pack2(dk0[r4 * 4 + 2] * a.d.scale, dk0[r4 * 4 + 3] * a.d.scale);
+                    *(uint2*)(op + C + d) = w;
+                    w.x = pack2(dk1[r4 * 4 + 0] * a.d.scale, dk1[r4 * 4 + 1] * a.d.scale);
+                    w.y = pack2(dk1[r4 * 4 + 2] * a.d.scale, dk1[r4 * 4 + 3] * a.d.scale);
+                    *(uint2*)(op + C + 32 + d) = w;
+                    w.x = pack2(dv0[r4 * 4 + 0], dv0[r4 * 4 + 1]);
+                    w.y = pack2(dv0[r4 * 4 + 2], dv0[r4 * 4 + 3]);
+                    *(uint2*)(op + 2 * C + d) = w;
+                    w.x = pack2(dv1[r4 * 4 + 0], dv1[r4 * 4 + 1]);
+                    w.y = pack2(dv1[r4 * 4 + 2], dv1[r4 * 4 + 3]);
+                    *(uint2*)(op + 2 * C + 32 + d) = w;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <typename Kn>
+static void seq_lds(Kn k, size_t bytes) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    (void)hipGetLastError();
+}
+
+bool seq3_supported(const AttnArgs& a) { return a.d.mode == 1 && a.N <= SEQ3_ROWS; }
+
+#define SEQ3_DISPATCH(KERN, lds, ...)                                                                               \
+    do {                                                                                                            \
+        const bool causal = a.d.causal_from > 0, drop = a.d.dropout_p > 0.f;                                        \
+        if (causal) {                                                                                               \
+            if (drop) { seq_lds(KERN<true, true>, lds); hipLaunchKernelGGL((KERN<true, true>), grid, dim3(256), lds, s, __VA_ARGS__); }   \
+            else { seq_lds(KERN<true, false>, lds); hipLaunchKernelGGL((KERN<true, false>), grid, dim3(256), lds, s, __VA_ARGS__); }      \
+        } else {                                                                                                    \
+            if (drop) { seq_lds(KERN<false, true>, lds); hipLaunchKernelGGL((KERN<false, true>), grid, dim3(256), lds, s, __VA_ARGS__); } \
+            else { seq_lds(KERN<false, false>, lds); hipLaunchKernelGGL((KERN<false, false>), grid, dim3(256), lds, s, __VA_ARGS__); }    \
+        }                                                                                                           \
+    } while (0)
+
+int seq3_fwd(void* stream, const AttnArgs& a, int problems) {
+    hipStream_t s = (hipStream_t)stream;
+    const int nprob = problems * a.d.heads;
+    const dim3 grid(nprob < 512 ? nprob : 512);
+    const size_t lds = 2 * SEQ3_IMG + SEQ3_ROWS * 4;
+    SEQ3_DISPATCH(seq_fwd3, lds, a, nprob);
+    return lav_check_launch("lav_attention_fwd(sequence)");
+}
+
+int seq3_bwd(void* stream, const AttnArgs& a, int problems, float* delta) {
+    hipStream_t s = (hipStream_t)stream;
+    const int nprob = problems * a.d.heads;
+    const dim3 grid(nprob < 512 ? nprob : 512);
+    const size_t lds1 = 2 * SEQ3_IMG + SEQ3_ROWS * 4, lds2 = 2 * SEQ3_IMG + SEQ3_ROWS * 8;
+    SEQ3_DISPATCH(seq_dq3, lds1, a, nprob, delta);
+    SEQ3_DISPATCH(seq_dkv3, lds2, a, nprob, (const float*)delta);
+    return lav_check_launch("lav_attention_bwd(sequence)");
+}

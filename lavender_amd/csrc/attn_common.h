@@ -29,6 +29,10 @@ int attn_setup(const lav_attn_desc* d, AttnArgs& a, int& problems);
 int win_persistent_fwd(void* stream, const AttnArgs& a);
 int win_persistent_bwd(void* stream, const AttnArgs& a, float* ndelta);     // dQ, dK, dV (+ bias gradient when a.dbias)
 int win_persistent_dbias(void* stream, const AttnArgs& a, const float* ndelta);
+// sequence mode, L <= 288 (attention_seq.hip)
+bool seq3_supported(const AttnArgs& a);
+int seq3_fwd(void* stream, const AttnArgs& a, int problems);
+int seq3_bwd(void* stream, const AttnArgs& a, int problems, float* delta);
 
 // fast window path: token rows from the precomputed per-window table instead of div/mod chains
 __device__ __forceinline__ int tok_row(const AttnArgs& a, int win, int i) {
