@@ -765,15 +765,21 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
 // 64 KB of direct-to-LDS writes = 2048 clk, exactly the MFMA time -- the k-loop sits near 47 % of the MFMA peak.
 // NW = 4 (2 x 2 waves of 128x128, 256 accumulator registers, one wave per SIMD, 128 KB of reads) was measured at HALF
 // the rate: with a single wave per SIMD nothing covers the LDS latency between the compiler's read/MFMA groups.
-template <bool AKC, bool BKC, unsigned F, int NW>
+// RF = 16-row fragments per wave: 8 -> 256-row tiles; 6 -> 192-row tiles (K-contiguous layouts with a specialised epilogue only):
+// a 45120 x 768 output is 531 tiles of 256 x 256 = 2.07 rounds on 256 CUs (a third of the last round's CUs idle for a whole
+// tile), but 705 tiles of 192 x 256 = 2.75 rounds of 3/4-size tiles.
+template <bool AKC, bool BKC, unsigned F, int NW, int RF = 8>
 __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
+    constexpr int BMT = 2 * RF * 16;                      // tile rows
+    constexpr int IPA = BMT / 8 / NW;                     // direct-to-LDS wave-instructions per A tile per wave (K-contiguous A)
+    static_assert(RF == 8 || (AKC && F != EF_ALL && F != EF_TNFLUSH && NW == 8), "192-row tiles: K-contiguous A, specialised epilogue");
     constexpr int WN = NW / 2;                            // wave grid 2 (m) x WN (n)
     constexpr int NJ = 16 / WN;                           // 16-column fragments per wave
     constexpr int IPW = 32 / NW;                          // direct-to-LDS wave-instructions per operand tile per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tiles_n = g.N / 256, tiles_m = (g.M + BIG_BM - 1) / BIG_BM;
+    const int tiles_n = g.N / 256, tiles_m = (g.M + BMT - 1) / BMT;
     const int nwg = tiles_m * tiles_n;
     // 1-D grid of nwg * splits blocks; hardware block b runs on XCD b % 8.  The bijective remap gives each XCD one
     // contiguous run of (split, tile) work items, split-major: blocks that share a k-range (and so the same rows of both
@@ -793,14 +799,14 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
         const int gw = min(g.group_n, tiles_n - cg * g.group_n);          // last group may be narrower
         tm = rem / gw; tn = cg * g.group_n + rem % gw;
     }
-    const int m0 = tm * BIG_BM, n0 = tn * 256;
+    const int m0 = tm * BMT, n0 = tn * 256;
     const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nk = (kend - kbeg) / BKT;
 
-    f32x4 acc[8][NJ];
+    f32x4 acc[RF][NJ];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < RF; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // TN: bias gradient (row sums of A^T) on the matrix cores against a ones fragment, wn == 0 waves of the n0 == 0 blocks
@@ -816,7 +822,7 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
     auto issue = [&](int kt) {
         char* st = smem + (kt & 1) * HUGE_STAGE;
         const int k0 = kbeg + kt * BKT;
-        if (AKC) big_glds<true, IPW>(st, g.A, g.lda, m0, g.M, k0, wave, lane);
+        if (AKC) big_glds<true, IPA>(st, g.A, g.lda, m0, g.M, k0, wave, lane);
         else huge_glds_strided<IPW>(st, g.A, g.lda, m0, g.M, k0, wave, lane);
         if (BKC) big_glds<true, IPW>(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);
         else huge_glds_strided<IPW>(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);
@@ -841,17 +847,17 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (kmode == 0) break;
-            bf16x8 fa[8], fb[NJ];
+            bf16x8 fa[RF], fb[NJ];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = AKC ? frag_read<true>(la, wm * 8 + i, ks, lane) : huge_frag_strided(la, wm * 8 + i, ks, lane);
+            for (int i = 0; i < RF; ++i) fa[i] = AKC ? frag_read<true>(la, wm * RF + i, ks, lane) : huge_frag_strided(la, wm * RF + i, ks, lane);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) fb[j] = BKC ? frag_read<true>(lb, wn * NJ + j, ks, lane) : huge_frag_strided(lb, wn * NJ + j, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < RF; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            if (!AKC && do_rowsum) {
+            if constexpr (!AKC) if (do_rowsum) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, acc1[i], 0, 0, 0);
             }
@@ -871,25 +877,29 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
 
     if (g.dbg & 1) return;
     if constexpr (NW == 8 && F != EF_ALL && F != EF_TNFLUSH) {
-        // specialised forward / input-gradient epilogues: every wave stages its own 128 x 64 accumulator block through a
-        // private LDS slice in two 64-row halves and stores it -- no block barriers, no waves idling while the other half
-        // of the tile is staged (the block-wide version below costs ~5.5 us per tile)
+        // specialised forward / input-gradient epilogues: every wave stages its own accumulator block through a private LDS slice
+        // in 64- or 32-row chunks and stores it in full 128-byte row pieces -- no block barriers.  Round 3 tried the epilogue straight
+        // from the accumulator registers (swapped MFMA operands + permuted B rows so that a lane holds row-contiguous columns, no LDS
+        // round trip): with 32-byte pieces per row per store instruction the STEP was 5.5 ms slower (83.0 vs 77.5 ms; isolated
+        // launches within +-3 %), with 64-byte pieces equal (77.9): partial-line writes and residual reads are what the step, run
+        // next to the weight-gradient stream, cannot afford.  The LDS-staged full-line form stays.
         constexpr int WS = 68;                            // private row stride (floats)
+        constexpr int CF = RF == 8 ? 4 : 2;               // 16-row fragments per staged chunk: 64-row halves (256-row tile) or 32-row thirds
         float* clw = (float*)smem + wave * (64 * WS);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {                     // unrolled: acc[] must be indexed with compile-time constants
+        for (int h = 0; h < RF / CF; ++h) {               // unrolled: acc[] must be indexed with compile-time constants
             if (!(g.dbg & 4)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < CF; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        clw[(i * 16 + (lane >> 4) * 4 + r) * WS + j * 16 + (lane & 15)] = acc[h * 4 + i][j][r];
+                        clw[(i * 16 + (lane >> 4) * 4 + r) * WS + j * 16 + (lane & 15)] = acc[h * CF + i][j][r];
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the slice is only read by this wave
             __builtin_amdgcn_wave_barrier();
-            gemm_epilogue<64, 64, F, 8, WS>(g, clw, m0 + wm * 128 + h * 64, n0 + wn * 64, split);
+            gemm_epilogue<CF * 16, 64, F, 8, WS>(g, clw, m0 + wm * (RF * 16) + h * (CF * 16), n0 + wn * 64, split);
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
         }
@@ -918,6 +928,8 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
 
 template <bool AKC, bool BKC, unsigned F = EF_ALL>
 __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 8>(g); }
+template <bool AKC, bool BKC, unsigned F>
+__global__ __launch_bounds__(512) void gemm_h192_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 8, 6>(g); }
 
 // ------------------------------------------------------------------------------------------------------
 // Ping-pong 256x256x32 kernels.  8 waves in two groups of four -- group g = wave >> 2 owns rows [128 g, 128 g + 128) of
@@ -1383,7 +1395,8 @@ static bool lav_gemm_pp_tn = getenv("LAV_GEMM_PP_TN") ? atoi(getenv("LAV_GEMM_PP
 // tiles then form an 8 x 4 block: 12 operand panels in its L2 instead of 15 for 2.7 rows x 12 columns; measured +8-12 % on the
 // 45120 x 3072 x 768 GEMMs and on 8192^3, nothing on narrower outputs).  LAV_GEMM_GROUP_N=0 restores n-fastest, other values force G.
 static int lav_gemm_group_n = getenv("LAV_GEMM_GROUP_N") ? atoi(getenv("LAV_GEMM_GROUP_N")) : -1;
-static int lav_gemm_dbg = 0;                               // probe hook: GemmArgs.dbg of the 256x256 kernel
+static int lav_gemm_h192 = getenv("LAV_GEMM_H192") ? atoi(getenv("LAV_GEMM_H192")) : 1;          // 192-row tiles for outputs that under-fill the last round of 256-row tiles
+static int lav_gemm_dbg = getenv("LAV_GEMM_DBG") ? atoi(getenv("LAV_GEMM_DBG")) : 0;                               // probe hook: GemmArgs.dbg of the 256x256 kernel
 static int lav_gemm_pp_dbg = 0;                            // ablation builds of the ping-pong kernel (probe only, wrong results): 1 no refills, 2 no fragment reads, 4 no MFMAs
 extern "C" int lav_gemm_select(int which, int value) {    // probe hook (within-process A/B): which 0 = ping-pong kernel on/off; returns the old value
     int old = -1;
@@ -1392,6 +1405,7 @@ extern "C" int lav_gemm_select(int which, int value) {    // probe hook (within-
     if (which == 2) { old = lav_gemm_pp_tn; lav_gemm_pp_tn = value != 0; }
     if (which == 5) { old = lav_gemm_dbg; lav_gemm_dbg = value; }
     if (which == 6) { old = lav_gemm_group_n; lav_gemm_group_n = value; }
+    if (which == 7) { old = lav_gemm_h192; lav_gemm_h192 = value; }
     return old;
 }
 
@@ -1450,8 +1464,8 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
                        S_BDR = EF_BIAS | EF_DROP | EF_RSCALE | EF_RES, S_BDRO = S_BDR | EF_O32;
     const unsigned fsel = !(fm & ~S_B) ? S_B : !(fm & ~S_BG) ? S_BG : !(fm & ~S_GC) ? S_GC : !(fm & ~S_BDR) ? S_BDR :
                           ((fm & EF_O32) && !(fm & ~S_BDRO)) ? S_BDRO : EF_ALL;
-    constexpr int lav_threads_gemm_huge_kernel = 512, lav_threads_gemm_big_kernel = 512;
-    (void)lav_threads_gemm_huge_kernel; (void)lav_threads_gemm_big_kernel;
+    constexpr int lav_threads_gemm_huge_kernel = 512, lav_threads_gemm_big_kernel = 512, lav_threads_gemm_h192_kernel = 512;
+    (void)lav_threads_gemm_huge_kernel; (void)lav_threads_gemm_big_kernel; (void)lav_threads_gemm_h192_kernel;
 #define LAV_LAUNCH_ONE(KERN, AKC_, BKC_, F_, GRID, LDS)                                                                   \
     do {                                                                                                                  \
         static bool attr_done = false;                                                                                    \
@@ -1502,6 +1516,19 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     static const double w_big = getenv("LAV_GEMM_BIG_W") ? atof(getenv("LAV_GEMM_BIG_W")) : 0.80;    // probe hook; 0.80 measured best once the dW stream fills partial rounds (0.88 before)
     const double f_small = fill(t_small, 512, 0.80), f_big = fill(t_big, 256, w_big);
     const double f_huge = (N % 256) == 0 ? fill(t_huge, 256, 1.0) : 0.0;
+    // 192-row tiles where they fill the machine better (narrow outputs: N = 768 at M = 45120 is 2.07 rounds of 256-row tiles)
+    const long t_h192 = (long)((M + 191) / 192) * (N / 256);
+    const double f_h192 = ((N % 256) == 0 && fsel != EF_ALL && lav_gemm_h192) ? fill(t_h192, 256, 0.97) : 0.0;
+    if (big && !lav_gemm_no_huge && f_h192 > f_huge + 0.02 && f_h192 >= f_big && f_h192 >= f_small) {
+        g.k_per_split = K;
+        g.dbg = lav_gemm_dbg; g.group_n = 0;
+        dim3 hgrid((unsigned)t_h192);
+#define LAV_H192(F_) { if (layout == 0) LAV_LAUNCH_ONE(gemm_h192_kernel, true, true, F_, hgrid, HUGE_LDS); else LAV_LAUNCH_ONE(gemm_h192_kernel, true, false, F_, hgrid, HUGE_LDS); }
+        if (fsel == S_B) LAV_H192(S_B) else if (fsel == S_BG) LAV_H192(S_BG) else if (fsel == S_GC) LAV_H192(S_GC)
+        else if (fsel == S_BDR) LAV_H192(S_BDR) else LAV_H192(S_BDRO)
+#undef LAV_H192
+        return lav_check_launch("lav_gemm_bf16");
+    }
     if (big && !lav_gemm_no_huge && f_huge >= f_big && f_huge >= f_small) {
         g.k_per_split = K;
         dim3 hgrid((unsigned)t_huge);
