@@ -60,6 +60,11 @@ void lav_decoder_destroy(void* dec);
  * event, so the call blocks only if the copy of the batch before the previous one is still in flight. */
 int lav_decoder_decode(void* dec, void* stream, int n_frames, const char* const* b64, const long* b64_len,
                        const lav_frame_xform* xf, int out_h, int out_w, const float* mean3, const float* std3, float* out);
+/* After lav_decoder_decode returned LAV_E_ARG because frames could not be decoded (bad base64, truncated / corrupt entropy stream,
+ * missing restart marker ...): the indices of ALL such frames of that call (returns their number; at most `capacity` are written).
+ * Nothing was enqueued by the failed call.  The caller drops those samples and decodes the rest -- the reference substitutes a
+ * zero clip for a sample whose frames cannot be read (main_pretrain_task_specific.py:95-106). */
+int lav_decoder_failed_frames(void* dec, int* frames, int capacity);
 /* Debug / test taps of the last decoded batch (device -> host copies, synchronous): the full-resolution RGB frame
  * (h * w * 3 bytes, after padding) of frame i. */
 int lav_decoder_read_rgb(void* dec, int frame, uint8_t* rgb, long capacity, int* w, int* h);

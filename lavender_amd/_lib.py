@@ -113,6 +113,7 @@ _PIPE_SIGS = {
     "lav_decoder_create": (vp, [i32]),
     "lav_decoder_destroy": (None, [vp]),
     "lav_decoder_decode": (i32, [vp, vp, i32, P(vp), P(i64), P(FrameXform), i32, i32, P(f32), P(f32), vp]),
+    "lav_decoder_failed_frames": (i32, [vp, P(i32), i32]),
     "lav_decoder_read_rgb": (i32, [vp, i32, vp, i64, P(i32), P(i32)]),
 }
 class MatDesc(C.Structure):                  # struct lav_mat_desc

@@ -136,17 +136,22 @@ class Agent_Base:
             json.dump(dict(self.args), open(f'{self.args.path_output}/args.json', 'w'), indent=2)
             self.save_model(0)
 
-    def save_model(self, ep):
-        """agent.py:164-180: rank-0 torch.save of the CPU state_dict under the reference's file name."""
+    def _save_state(self, filename):
+        """rank-0 torch.save of the CPU state_dict as `filename` under args.path_output (every rank must call this: with
+        ZeRO-1 all ranks take part in re-assembling the fp32 masters)."""
         if self.dp is not None:
-            self.dp.gather_master()                         # ZeRO-1: every rank takes part in re-assembling the fp32 masters
+            self.dp.gather_master()
         if is_main_process():
             output_dir = self.args.path_output
             os.makedirs(output_dir, exist_ok=True)
             sd = {k: v.cpu() if isinstance(v, torch.Tensor) else v for k, v in self._unwrapped().state_dict().items()}
-            torch.save(sd, f"{output_dir}/ckpt_violet_{self.args.task}_{ep}.pt")
+            torch.save(sd, f"{output_dir}/{filename}")
             if self.log is not None:
                 json.dump(self.log, open(f"{output_dir}/log.json", 'w'), indent=2)
+
+    def save_model(self, ep):
+        """agent.py:164-180: ckpt_violet_{task}_{ep}.pt."""
+        self._save_state(f"ckpt_violet_{self.args.task}_{ep}.pt")
 
     def log_memory(self, ep=-1, step=-1):
         step_str = f"global step: {self.global_step}," if ep == -1 and step == -1 else f"ep: {ep}, step: {step},"

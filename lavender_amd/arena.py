@@ -136,8 +136,18 @@ class ParamArena:
             K.transpose_batched(self._t_n, self._t_desc, self._t_tiles, self.half_full, self.half_t)
 
     # -- bf16 working copy -------------------------------------------------------------------------
+    # ZeRO-1 (dp.ZeroOneReducer): after a sharded optimizer step only this rank's slice of the fp32 master is current until
+    # dp.gather_master() -- a collective, so it cannot be triggered from a single rank's read.  Readers of the master check this.
+    masters_sharded = False
+
+    def require_full_master(self, what):
+        if self.masters_sharded:
+            raise RuntimeError(f"{what}: the fp32 masters are sharded across ranks (ZeRO-1 step taken); call "
+                               "agent.dp.gather_master() on EVERY rank first (Agent_Base.save_model does)")
+
     def sync_half(self):
         """Refresh the bf16 working copies from the fp32 master (after load_state_dict / a foreign optimizer)."""
+        self.require_full_master("ParamArena.sync_half")
         K.cast_bf16(self.master, self.half, self.total)
         self.sync_transposed()
         self.stale = False

@@ -622,6 +622,7 @@ struct Decoder {
     uint32_t* rgb = nullptr; size_t rgb_cap = 0;      // pixels
     uint32_t* tmp = nullptr; size_t tmp_cap = 0;      // pixels
     std::vector<FrameDesc> last;                      // host copy of the last batch's descriptors (debug taps)
+    std::vector<int> failed;                          // frames of the last lav_decoder_decode call that could not be decoded
 };
 
 template <typename T>
@@ -682,8 +683,15 @@ extern "C" int lav_decoder_decode(void* h, void* stream, int n_frames, const cha
         const char* e = jpeg_parse(jpg[i].data(), n, hdr[i], true);
         if (e) err[i] = e;
     });
-    for (int i = 0; i < n_frames; ++i)
-        if (!err[i].empty()) { lav_set_error("lav_decoder_decode: frame %d: %s", i, err[i].c_str()); return LAV_E_ARG; }
+    D->failed.clear();
+    auto report = [&]() {                                   // every unreadable frame of the batch, first message
+        int first = -1;
+        for (int i = 0; i < n_frames; ++i)
+            if (!err[i].empty()) { D->failed.push_back(i); if (first < 0) first = i; }
+        if (first >= 0) lav_set_error("lav_decoder_decode: frame %d: %s (%d unreadable frame(s) in the batch)", first, err[first].c_str(), (int)D->failed.size());
+        return first >= 0;
+    };
+    if (report()) return LAV_E_ARG;
     // ---- layout of this batch --------------------------------------------------------------------------------------
     std::vector<FrameDesc> desc(n_frames);
     size_t n_tab = 0, n_coef = 0, n_plane = 0, n_rgb = 0, n_tmp = 0;
@@ -741,8 +749,7 @@ extern "C" int lav_decoder_decode(void* h, void* stream, int n_frames, const cha
         if (f.need_v) resample_tables(f.ph, f.rh, f.crop_y, out_h, f.ky, tab + f.by_off, tab + f.ky_off);
         if (f.need_h) resample_tables(f.pw, f.rw, f.crop_x, out_w, f.kx, tab + f.bx_off, tab + f.kx_off);
     });
-    for (int i = 0; i < n_frames; ++i)
-        if (!err[i].empty()) { lav_set_error("lav_decoder_decode: frame %d: %s", i, err[i].c_str()); return LAV_E_ARG; }
+    if (report()) return LAV_E_ARG;
     for (int i = 0; i < n_frames; ++i) {                    // rows the vertical pass reads
         FrameDesc& f = desc[i];
         if (f.need_v) {
@@ -769,6 +776,14 @@ extern "C" int lav_decoder_decode(void* h, void* stream, int n_frames, const cha
                        (const uint32_t*)D->tmp, dtab, out, out_h, out_w, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     D->last = desc;
     return lav_check_launch("lav_decoder_decode");
+}
+
+extern "C" int lav_decoder_failed_frames(void* h, int* frames, int capacity) {
+    Decoder* D = (Decoder*)h;
+    if (!D) return LAV_E_ARG;
+    const int n = (int)D->failed.size();
+    for (int i = 0; i < n && i < capacity; ++i) frames[i] = D->failed[i];
+    return n;
 }
 
 extern "C" int lav_decoder_read_rgb(void* h, int frame, uint8_t* rgb, long capacity, int* w, int* hh) {

@@ -136,6 +136,12 @@ class FrameDecoder:
         L.check(L.lib.lav_decoder_decode(self._h, st, n, ptr, ln, xf, size, size, self._mean, self._std, out.data_ptr()), "lav_decoder_decode")
         return out
 
+    def failed_frames(self):
+        """Indices (into the plan list) of the frames the last failed decode() call could not read."""
+        buf = (L.i32 * 4096)()
+        n = L.lib.lav_decoder_failed_frames(self._h, buf, 4096)
+        return [buf[i] for i in range(max(0, min(n, 4096)))]
+
     def last_rgb(self, i):
         """Full-resolution RGB (H, W, 3) uint8 of frame i of the last batch (test tap)."""
         cap = 1 << 26
@@ -385,7 +391,7 @@ class PretrainLoader:
         B = len(items)
         with torch.cuda.stream(stream):                    # owned by the side stream's pool; the consumer records its own use
             img = torch.empty((B, T, 3, S, S), dtype=torch.float32, device="cuda")
-        plans, slots = [], []
+        plans, slots, owner = [], [], []
         for b, (p, _, _) in enumerate(items):
             if p is None or len(p) != T:
                 if p is not None:
@@ -395,8 +401,24 @@ class PretrainLoader:
                 continue
             plans += p
             slots += [b * T + t for t in range(T)]
-        if plans:
-            self.decoder.decode(plans, S, out=img, slots=slots, stream=stream)
+            owner += [b] * T
+        while plans:
+            try:
+                self.decoder.decode(plans, S, out=img, slots=slots, stream=stream)
+                break
+            except L.LavenderHipError as e:
+                # a frame whose header parsed but whose entropy stream is truncated / corrupt only fails here: the reference
+                # substitutes a zero clip for THAT sample (main_pretrain_task_specific.py:95-106), the rest of the batch decodes
+                bad = {owner[i] for i in self.decoder.failed_frames()}
+                if not bad:
+                    raise
+                print(f"Failed to decode image binaries of sample(s) {sorted(bad)} of a batch for dataset {getattr(self.ds, 'dataset', '?')}, "
+                      f"split {self.ds.split}: {e}")
+                with torch.cuda.stream(stream):
+                    for b in bad:
+                        img[b].zero_()
+                keep = [i for i, b in enumerate(owner) if b not in bad]
+                plans, slots, owner = [plans[i] for i in keep], [slots[i] for i in keep], [owner[i] for i in keep]
         # txt / mask stay on the host (pinned), as the reference's DataLoader hands them over: the trainer masks them on the
         # CPU before the copy (main_pretrain_mlm.py:215-220)
         batch = {"img": img, "txt": torch.stack([t for _, t, _ in items]).pin_memory(),
@@ -417,7 +439,9 @@ class PretrainLoader:
         if not self.prefetch:
             for items in self._batches():
                 batch, ev = self._collate(items, self._stream)
-                torch.cuda.current_stream().wait_event(ev)
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                batch["img"].record_stream(cur)          # allocated in the side stream's pool, consumed on the current stream
                 yield batch
             return
         q = queue.Queue(maxsize=2)
@@ -428,28 +452,50 @@ class PretrainLoader:
             g.manual_seed(base)
             self.ds.set_rng(random.Random(base), g)
 
+        stop = threading.Event()
+
+        def put(x):                                        # gives up when the consumer has gone away
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
         def work():
             try:
                 torch.cuda.set_device(dev)
                 for items in self._batches():
-                    q.put(self._collate(items, self._stream))
-                q.put(None)
+                    if stop.is_set() or not put(self._collate(items, self._stream)):
+                        return
+                put(None)
             except BaseException as e:                     # surfaced in the consumer
-                q.put(e)
+                put(e)
         th = threading.Thread(target=work, daemon=True)
         th.start()
-        while True:
-            got = q.get()
-            if got is None:
-                break
-            if isinstance(got, BaseException):
-                raise got
-            batch, ev = got
-            cur = torch.cuda.current_stream()
-            cur.wait_event(ev)
-            batch["img"].record_stream(cur)
-            yield batch
-        th.join()
+        try:
+            while True:
+                got = q.get()
+                if got is None:
+                    break
+                if isinstance(got, BaseException):
+                    raise got
+                batch, ev = got
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                batch["img"].record_stream(cur)
+                yield batch
+        finally:
+            # a consumer that stops early (break / exception / GeneratorExit) must not leave the worker blocked in q.put holding
+            # GPU batches, sharing the decoder and the side stream with the next __iter__
+            stop.set()
+            while True:
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    break
+            th.join()
 
 
 def get_dl(ds, args, rank=0, world=1):

@@ -219,6 +219,7 @@ class ZeroOneReducer(ArenaReducer):
             dist.all_reduce(hf, op=dist.ReduceOp.SUM, group=self.group)
         arena.sync_transposed()
         self._master_stale = True
+        arena.masters_sharded = True
 
     def gather_master(self):
         """fp32 masters of every shard on every rank (before state_dict() / a checkpoint)."""
@@ -230,3 +231,4 @@ class ZeroOneReducer(ArenaReducer):
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
         a.master.copy_(full[:a.total])
         self._master_stale = False
+        a.masters_sharded = False

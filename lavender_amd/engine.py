@@ -637,7 +637,12 @@ class CrossEntropyFn(torch.autograd.Function):
     def forward(ctx, logits, labels, count, keep_logits=False):
         if keep_logits and ctx.needs_input_grad[0]:
             src = logits
-            logits = torch.empty_strided(src.shape, src.stride(), dtype=src.dtype, device=src.device) if src.stride(-1) == 1 else src.clone()
+            if src.dim() == 2 and src.stride(-1) == 1:
+                # a FULL (rows, row stride) buffer with a [:, :V] view: the scale kernels below run over rows * stride elements,
+                # so the storage must not end at the last row's V-th column (empty_strided's does)
+                logits = torch.empty((src.shape[0], src.stride(0)), dtype=src.dtype, device=src.device)[:, :src.shape[1]]
+            else:
+                logits = src.clone()
             logits.copy_(src)
         V = logits.shape[-1]
         f32 = logits.dtype == torch.float32

@@ -136,6 +136,13 @@ class LAVENDER_Base(nn.Module):
 
     build_arena = arena
 
+    def state_dict(self, *a, **kw):
+        """nn.Module.state_dict over the fp32 masters; refuses to hand out a half-updated copy after a ZeRO-1 step (the masters
+        are then sharded: gather them on every rank first, as Agent_Base.save_model does)."""
+        if self._lav_arena is not None:
+            self._lav_arena.require_full_master("state_dict")
+        return super().state_dict(*a, **kw)
+
     def sync_weights(self):
         """Call after modifying parameters in place outside the built-in optimizer."""
         self.arena().sync_half()

@@ -125,6 +125,11 @@ class Agent_Pretrain_MLM(Agent_Base):
         self.patch_size = self._unwrapped().patch_size
         self.log = {dataset: defaultdict(list) for dataset in getattr(self.args, "dataset", [])}
 
+    def save_model(self, ep, dataset="init", part=0):
+        """main_pretrain_task_specific.py:282-297: one checkpoint per (dataset, part, epoch) of the pre-training loop,
+        ckpt_violet_pretrain_{dataset}_{part}_{ep}.pt -- the names the downstream configs of the reference load."""
+        self._save_state(f"ckpt_violet_pretrain_{dataset}_{part}_{ep}.pt")
+
     def cal_vtm_loss(self, txt, out, ans, is_train=True, count=None):
         if is_train:
             return self.loss_func(out.flatten(0, len(out.shape) - 2), ans.flatten(0, len(ans.shape) - 1), count)

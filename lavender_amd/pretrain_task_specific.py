@@ -79,6 +79,11 @@ class Agent_Pretrain(Agent_Base):
         self.patch_size = self._unwrapped().patch_size
         self.log = {dataset: defaultdict(list) for dataset in getattr(self.args, "dataset", [])}
 
+    def save_model(self, ep, dataset="init", part=0):
+        """main_pretrain_task_specific.py:282-297: one checkpoint per (dataset, part, epoch) of the pre-training loop,
+        ckpt_violet_pretrain_{dataset}_{part}_{ep}.pt -- the names the downstream configs of the reference load."""
+        self._save_state(f"ckpt_violet_pretrain_{dataset}_{part}_{ep}.pt")
+
     def masking(self, txt, mask, p_mask=0.15):
         """main_pretrain_task_specific.py:186-209 (same procedure as the MLM agent)."""
         return masking(txt, mask, (self.cls_token_id, self.sep_token_id, self.pad_token_id, self.mask_token_id), p_mask)

@@ -164,7 +164,7 @@ def pretrain_mlm_forward(model, batch, taps=None):
     img, txt, mask = batch["img"], batch["txt"], batch["mask"]
     _B, _X = txt.shape
     _O = min(_B, model.vtm_batch)
-    model.arena()
+    model.arena().require_full_master("fp32 validation forward")      # reads the fp32 masters
     f_img = enc_video(model.enc_img, img, taps)
     f_txt = enc_txt(model.enc_txt, txt)
     Lv = f_img.shape[1]

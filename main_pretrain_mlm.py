@@ -48,11 +48,11 @@ class SyntheticPretrain(torch.utils.data.Dataset):
 
 def real_data(args):
     """{dataset: txt json} and a tokenizer when the reference's data layout is present, else None."""
-    data_dir = getattr(args, "data_dir", None)
-    if not data_dir or not all(os.path.exists(f"{data_dir}/txt_{d}.json") for d in args.dataset) or not os.path.isdir(str(args.tokenizer)):
+    dirs = {d: (args.dataset[d] if isinstance(args.dataset, dict) else getattr(args, "data_dir", None)) for d in args.dataset}   # :263-266
+    if not all(v and os.path.exists(f"{v}/txt_{d}.json") for d, v in dirs.items()) or not os.path.isdir(str(args.tokenizer)):
         return None
     import transformers
-    return ({d: json.load(open(f"{data_dir}/txt_{d}.json")) for d in args.dataset},
+    return ({d: json.load(open(f"{v}/txt_{d}.json")) for d, v in dirs.items()},
             transformers.AutoTokenizer.from_pretrained(args.tokenizer))
 
 
@@ -61,10 +61,12 @@ def train_on_tsv(args, txt_data, tokzr):
     from lavender_amd.data import Dataset_Pretrain_MLM, get_dl
     rank, world = get_rank(), get_world_size()
     loaders, n = {}, 0
+    data_dirs = {}
     for d in args.dataset:
         size_part = args.size_part if isinstance(args.size_part, int) else args.size_part[d]
-        loaders[f"{d}-val"] = get_dl(Dataset_Pretrain_MLM(args, txt_data[d], d, "val", data_dir=args.data_dir, tokzr=tokzr), args, rank, world)
-        loaders[f"{d}-train-0"] = get_dl(Dataset_Pretrain_MLM(args, txt_data[d], d, "train", 0, data_dir=args.data_dir, tokzr=tokzr), args, rank, world)
+        data_dirs[d] = args.dataset[d] if isinstance(args.dataset, dict) else args.data_dir     # main_pretrain_mlm.py:263-266
+        loaders[f"{d}-val"] = get_dl(Dataset_Pretrain_MLM(args, txt_data[d], d, "val", data_dir=data_dirs[d], tokzr=tokzr), args, rank, world)
+        loaders[f"{d}-train-0"] = get_dl(Dataset_Pretrain_MLM(args, txt_data[d], d, "train", 0, data_dir=data_dirs[d], tokzr=tokzr), args, rank, world)
         n += len(loaders[f"{d}-train-0"]) * size_part
     args.max_iter = n * args.size_epoch
     model = LA.LAVENDER_Pretrain_MLM(args, tokzr)
@@ -79,12 +81,15 @@ def train_on_tsv(args, txt_data, tokzr):
             size_part = args.size_part if isinstance(args.size_part, int) else args.size_part[d]
             for part in range(size_part):
                 key = f"{d}-train-{part}"
-                dl_tr = loaders.get(key) or get_dl(Dataset_Pretrain_MLM(args, txt_data[d], d, "train", part, data_dir=args.data_dir, tokzr=tokzr),
+                dl_tr = loaders.get(key) or get_dl(Dataset_Pretrain_MLM(args, txt_data[d], d, "train", part, data_dir=data_dirs[d], tokzr=tokzr),
                                                    args, rank, world)
                 dl_tr.sampler.set_epoch(e + 1)
                 ls_tr = agent.go_dl(e + 1, dl_tr, True)
                 ac_vl = agent.go_dl(e + 1, loaders[f"{d}-val"], False)
-                agent.save_model(e + 1)
+                for k in ls_tr:                                # main_pretrain_mlm.py:321-323
+                    agent.log[d]['ls_%s' % k].append(ls_tr[k])
+                    agent.log[d]['ac_%s' % k].append(ac_vl[k])
+                agent.save_model(e + 1, d, part)               # ckpt_violet_pretrain_{dataset}_{part}_{ep}.pt (:326)
                 if is_main_process():
                     print(f"Ep {e + 1}, dataset {d}, part {part}: {json.dumps(ls_tr)}, {json.dumps(ac_vl)}")
 

@@ -71,3 +71,24 @@ def test_two_agent_steps_match_the_reference(golden_dir):
             print(f"{k}: cosine of the update vs the reference {cos:.4f}")
             assert cos > 0.99, (k, cos)                     # measured: >= 0.9998
     print("worst update cosine", worst)
+
+
+def test_pretrain_agents_write_the_reference_checkpoint_names(tmp_path):
+    """main_pretrain_task_specific.py:282-297 / main_pretrain_mlm.py:326: one file per (dataset, part, epoch),
+    ckpt_violet_pretrain_{dataset}_{part}_{ep}.pt -- parts of an epoch must not overwrite each other; the generic agents keep
+    agent.py:164-180's ckpt_violet_{task}_{ep}.pt."""
+    import lavender_amd as LA
+    cfg = dict(hf_cfg("micro"), hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    args = make_args("micro", "micro", 2, txt_backbone=cfg, fusion_encoder=cfg, tokenizer=cfg, lr=2e-5, decay=1e-3, max_iter=100,
+                     max_grad_norm=1.0, vis_backbone_lr_mul=1)
+    args.path_output, args.task, args.dataset = str(tmp_path), "pretrain", ["webvid", "cc3m"]
+    m = LA.LAVENDER_Pretrain_MLM(args, Tok()).cuda()
+    ag = LA.Agent_Pretrain_MLM(args, m)
+    ag.log["webvid"]["ls_mtm"].append(1.0)
+    ag.save_model(0)
+    ag.save_model(1, "webvid", 0)
+    ag.save_model(1, "webvid", 1)
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["ckpt_violet_pretrain_init_0_0.pt", "ckpt_violet_pretrain_webvid_0_1.pt", "ckpt_violet_pretrain_webvid_1_1.pt", "log.json"], names
+    sd = torch.load(os.path.join(tmp_path, "ckpt_violet_pretrain_webvid_1_1.pt"))
+    assert set(sd) == set(m.state_dict())

@@ -60,7 +60,11 @@ def _worker(rank, world, port, q, zero=False):
     agent.optzr.step(max_norm=1.0, dp=agent.dp)
     if zero:
         assert m.arena().m.numel() == hi - lo                                     # optimizer state for the own shard only
+        for reader in (m.state_dict, m.arena().sync_half):                        # stale-master readers refuse until the gather
+            with pytest.raises(RuntimeError, match="sharded"):
+                reader()
     agent.dp.gather_master()
+    m.state_dict()
     torch.cuda.synchronize()
     w1 = m.arena().master
     same16 = bool(torch.equal(m.arena().half.float(), w1.bfloat16().float()))     # bf16 working copy == rounded masters everywhere

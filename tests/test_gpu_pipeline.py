@@ -169,6 +169,46 @@ def test_decoder_rejects_bad_input():
         D.jpeg_size(b"")
 
 
+def test_loader_substitutes_a_zero_clip_for_a_sample_with_a_corrupt_entropy_stream(tmp_path, gold, golden_dir):
+    """main_pretrain_task_specific.py:95-106: a sample whose frames cannot be decoded becomes a zero clip, the rest of the batch is
+    untouched.  A JPEG whose header parses but whose entropy stream is truncated is only detected inside lav_decoder_decode: the
+    loader asks lav_decoder_failed_frames which frames failed, zeroes their samples and decodes the others."""
+    from lavender_amd import data as D
+    tsvp = os.path.join(golden_dir, "msrvtt_2rows.tsv")
+    rows = [l.rstrip("\n").split("\t") for l in open(tsvp)]
+    jpg = base64.b64decode(rows[1][2])
+    sos = jpg.index(b"\xff\xda")
+    jpg = jpg[:sos + 300] + b"\xfe" * 3000 + jpg[sos + 3300:]             # header intact (D.jpeg_size works), the scan is garbage:
+    rows[1][2] = base64.b64encode(jpg).decode()                            # long runs of one-bits are not a Huffman code
+    assert D.jpeg_size(rows[1][2].encode()) == (320, 240)
+    bad = os.path.join(tmp_path, "bad.tsv")
+    with open(bad, "w") as f:
+        for r in rows:
+            f.write("\t".join(r) + "\n")
+    txt = {"val": {k: [f"a video of {k} playing"] for k in gold["tsv_ids"].tolist()}}
+    args = _args(img_transform=["img_center_crop"])
+    out = {}
+    for name, path in (("good", tsvp), ("bad", bad)):
+        ds = D.Dataset_Pretrain(args, txt, path, None, split="val", dataset="msrvtt", tokzr=WordTok())
+        for prefetch in (False, True):
+            batches = list(D.PretrainLoader(ds, args, prefetch=prefetch))
+            assert len(batches) == 1
+            out[name, prefetch] = batches[0]["img"].clone()
+    for prefetch in (False, True):
+        g, b = out["good", prefetch], out["bad", prefetch]
+        assert torch.equal(b[0], g[0]) and float(g[1].abs().sum()) > 0 and float(b[1].abs().sum()) == 0.0
+    # a consumer that stops early does not leave the prefetch thread behind
+    import threading
+    n0 = threading.active_count()
+    ds = D.Dataset_Pretrain(args, txt, tsvp, None, split="val", dataset="msrvtt", tokzr=WordTok())
+    a1 = _args(img_transform=["img_center_crop"]); a1.size_batch = 1
+    for _ in D.PretrainLoader(ds, a1, prefetch=True):
+        break
+    import time
+    time.sleep(0.5)
+    assert threading.active_count() <= n0
+
+
 def test_agent_trains_and_evaluates_from_the_tsv_loader(tmp_path, golden_dir):
     """End to end as main_pretrain_mlm.py:251-328 drives it: Dataset_Pretrain_MLM over files named by the reference's scheme,
     the prefetching GPU loader, host masking, prepare_batch, step (train) and the eval branch, on the micro model."""
