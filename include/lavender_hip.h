@@ -286,6 +286,9 @@ typedef struct lav_mat_desc {
 int lav_transpose_bf16_batched(void* stream, int n_mats, const lav_mat_desc* descs_dev, int total_tiles, const void* src_bf16,
                                void* dst_bf16);
 int lav_cast_f32_to_bf16(void* stream, long n, const float* in, void* out);
+/* bf16 -> fp32: the summed half-precision gradient buckets of the data-parallel exchange (utils/deepspeed.py:20-28 trains with
+ * fp16 gradients) back into the fp32 gradient arena; both buffers 16-byte aligned. */
+int lav_cast_bf16_to_f32(void* stream, long n, const void* in, float* out);
 int lav_fill_droppath(void* stream, int n_blocks, int B, const float* keep_prob, uint32_t seed, float* scale);
 
 /* ---------------------------------------------------------------------------------------------

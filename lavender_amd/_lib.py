@@ -86,6 +86,7 @@ _SIGS = {
     "lav_sumsq_f32": (i32, [vp, i64, vp, vp]),
     "lav_adamw_step": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, P(f32), P(f32), f32, f32, f32, i32, vp, f32, f32]),
     "lav_cast_f32_to_bf16": (i32, [vp, i64, vp, vp]),
+    "lav_cast_bf16_to_f32": (i32, [vp, i64, vp, vp]),
     "lav_fill_droppath": (i32, [vp, i32, i32, vp, u32, vp]),
     # fp32-I/O validation mode (csrc/validate.hip)
     "lav_v_gemm_f32": (i32, [vp, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, vp, i64]),

@@ -193,7 +193,10 @@ class Agent_Base:
         arena gradient reducer (lavender_amd.dp)."""
         if get_world_size() > 1:
             from .dp import ArenaReducer, ZeroOneReducer
+            # args.grad_comm_bf16: half-precision gradient exchange (the reference's ZeRO-1 config uses fp16 gradients,
+            # utils/deepspeed.py:20-28); default fp32 = DDP's exact sum
+            gd = "bf16" if getattr(self.args, "grad_comm_bf16", False) else None
             if getattr(self.args, "deepspeed", False):
-                self.dp = ZeroOneReducer(self._unwrapped())
+                self.dp = ZeroOneReducer(self._unwrapped(), grad_dtype=gd)
             else:
-                self.dp = ArenaReducer(self._unwrapped())
+                self.dp = ArenaReducer(self._unwrapped(), grad_dtype=gd)

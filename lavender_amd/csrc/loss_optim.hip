@@ -343,6 +343,27 @@ __global__ __launch_bounds__(256) void cast_kernel(long n, const float* in, bf16
         for (long i = n4 * 4; i < n; ++i) out[i] = f2bf(in[i]);
 }
 
+// bf16 -> fp32 (the summed half-precision gradient buckets of the data-parallel exchange back into the fp32 gradient arena)
+__global__ __launch_bounds__(256) void widen_kernel(long n, const bf16_t* __restrict__ in, float* __restrict__ out) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 256 * 8) {
+        if (i + 8 <= n) {
+            float f[8];
+            unpack8(*(const uint4*)(in + i), f);
+            *(float4*)(out + i) = *(const float4*)&f[0]; *(float4*)(out + i + 4) = *(const float4*)&f[4];
+        } else {
+            for (long k = i; k < n; ++k) out[k] = bf2f(in[k]);
+        }
+    }
+}
+
+extern "C" int lav_cast_bf16_to_f32(void* stream, long n, const void* in, float* out) {
+    LAV_REQUIRE(n > 0 && in && out && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "lav_cast_bf16_to_f32: bad arguments (16-byte aligned buffers)");
+    int grid = (int)((n / 8 + 255) / 256 > 4096 ? 4096 : (n / 8 + 255) / 256);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)in, out);
+    return lav_check_launch("lav_cast_bf16_to_f32");
+}
+
 extern "C" int lav_cast_f32_to_bf16(void* stream, long n, const float* in, void* out) {
     LAV_REQUIRE(n > 0 && in && out, "lav_cast_f32_to_bf16: bad arguments");
     int grid = (int)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);

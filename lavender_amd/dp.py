@@ -23,6 +23,16 @@ Two modes (Agent_Base.prepare_dist_model picks by args.deepspeed, as the referen
   working copy is all-gathered.  The fp32 masters of the other shards go stale and are re-assembled on demand
   (gather_master(): before a checkpoint).
 
+Half-precision exchange (`grad_dtype="bf16"`, args.grad_comm_bf16 / LAV_GRAD_COMM_BF16=1; default fp32 = DDP's exact semantics):
+buckets of at least 1 MB are cast into a bf16 staging arena on the comm stream (lav_cast_f32_to_bf16), summed by the
+collective in bf16, and widened back into the fp32 gradient arena at finish() (lav_cast_bf16_to_f32): 443 MB instead of 886 MB
+over xGMI -- the reference's ZeRO-1 configuration trains with fp16 gradients (utils/deepspeed.py:20-28).  Every rank widens
+the same bf16 sums, so replicas stay bit-identical.  Small ranges (LayerNorm / bias / embedding rows) stay fp32.
+
+Why the comm stream may wait for "everything queued so far" on the weight-gradient stream (_comm_waits_for_producers): that
+stream is FIFO, and the last weight-gradient kernel of a finished range is the youngest kernel on it when the range's event
+fires -- everything older has to complete before it anyway, so a per-range event would release the exchange at the same time.
+
 Contract (both): exactly ONE backward per optimizer step may raise the overlap events; gradient accumulation goes through
 begin_step(last_micro_step=False) (events ignored, everything exchanged by finish()).  An event that arrives twice in one
 armed step -- the video encoder ran twice, or loss.backward() was called twice -- raises instead of silently summing a
@@ -42,12 +52,19 @@ def _backend(group):
 class ArenaReducer:
     zero_stage = 0
 
-    def __init__(self, model, bucket_mb=64, group=None):
+    def __init__(self, model, bucket_mb=64, group=None, grad_dtype=None):
+        import os
         self.model = model
         self.group = group
+        if grad_dtype is None:
+            grad_dtype = "bf16" if os.environ.get("LAV_GRAD_COMM_BF16", "0") != "0" else "fp32"
+        assert grad_dtype in ("fp32", "bf16")
+        self.grad_dtype = grad_dtype
+        self._g16 = None                                       # bf16 staging arena (allocated on first use)
+        self._widen = []                                       # (lo, hi) buckets whose bf16 sums finish() widens back
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        self.bucket_elems = max(64, int(bucket_mb * (1 << 20) // 4) // 64 * 64)     # 64-element multiples: bucket edges stay 16-byte aligned in bf16
         a = model.arena()
         # identical initial parameters on every rank (DDP broadcasts from rank 0 at wrap time)
         dist.broadcast(a.master, src=0, group=group)
@@ -109,6 +126,27 @@ class ArenaReducer:
             if dev == self.model.arena().grad.device:
                 self._stream.wait_stream(st)
 
+    HALF_MIN_ELEMS = 1 << 18                                  # buckets below 1 MB of fp32 stay fp32
+
+    def _narrow(self, g, b0, b1):
+        """fp32 gradient bucket -> its slot of the bf16 staging arena (on the current = comm stream); None if it stays fp32"""
+        if self.grad_dtype != "bf16" or b1 - b0 < self.HALF_MIN_ELEMS or (b0 % 8) != 0:
+            return None
+        if self._g16 is None:
+            self._g16 = torch.empty(g.numel(), dtype=torch.bfloat16, device=g.device)
+        h = self._g16[b0:b1]
+        if g.is_cuda:
+            from . import hip as K
+            K.cast_bf16(g[b0:b1], h, b1 - b0)
+        else:
+            h.copy_(g[b0:b1])                                  # CPU (gloo tests)
+        self._widen.append((b0, b1))
+        return h
+
+    def _exchange(self, t, b0, **kw):
+        """the collective of this reducer on the bucket that starts at arena element b0: sum all-reduce"""
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, **kw)
+
     def _reduce(self, ranges):
         g = self.model.arena().grad
         if self._stream is not None:
@@ -116,12 +154,25 @@ class ArenaReducer:
             with torch.cuda.stream(self._stream):
                 for lo, hi in ranges:
                     for b0, b1 in self.buckets(lo, hi):
-                        self._works.append(dist.all_reduce(g[b0:b1], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                        h = self._narrow(g, b0, b1)
+                        self._works.append(self._exchange(g[b0:b1] if h is None else h, b0, async_op=True))
         else:
             for lo, hi in ranges:
                 for b0, b1 in self.buckets(lo, hi):
-                    dist.all_reduce(g[b0:b1], op=dist.ReduceOp.SUM, group=self.group)
+                    h = self._narrow(g, b0, b1)
+                    self._exchange(g[b0:b1] if h is None else h, b0)
         self._done.extend(ranges)
+
+    def _widen_back(self):
+        """bf16 sums -> fp32 gradient arena (after the collectives of those buckets have completed on this stream)"""
+        g = self.model.arena().grad
+        for b0, b1 in self._widen:
+            if g.is_cuda:
+                from . import hip as K
+                K.widen_bf16(self._g16[b0:b1], g[b0:b1], b1 - b0)
+            else:
+                g[b0:b1].copy_(self._g16[b0:b1])
+        self._widen = []
 
     def _on_event(self, name):
         if not self._armed:
@@ -155,7 +206,10 @@ class ArenaReducer:
             with torch.cuda.stream(self._stream):
                 for w in self._works:
                     w.wait()
+                self._widen_back()
             torch.cuda.current_stream().wait_stream(self._stream)
+        else:
+            self._widen_back()
         self._works, self._done, self._fired, self._armed = [], [], set(), True
 
     # ---- optimizer hook (identical replicas: plain step) -----------------------------------------------------------------
@@ -170,8 +224,8 @@ class ZeroOneReducer(ArenaReducer):
     """DeepSpeed ZeRO stage 1 over the arena (see the module docstring)."""
     zero_stage = 1
 
-    def __init__(self, model, group=None):
-        super().__init__(model, bucket_mb=64, group=group)
+    def __init__(self, model, group=None, grad_dtype=None):
+        super().__init__(model, bucket_mb=64, group=group, grad_dtype=grad_dtype)
         a = model.arena()
         align = 64
         self.shard = ((a.total + self.world - 1) // self.world + align - 1) // align * align
@@ -182,25 +236,28 @@ class ZeroOneReducer(ArenaReducer):
             buf = getattr(a, name, None)
             if buf is not None and buf.numel() < self.padded:
                 raise RuntimeError(f"ZeroOneReducer: arena.{name} has no room for {self.world} shards of {self.shard} elements")
-        self.early_ranges, self.stage_ranges = [], {}          # one reduce-scatter at finish(): no early exchange in this mode
         self._nccl = _backend(group) == "nccl"
         self._master_stale = False
 
-    def _on_event(self, name):
-        return
+    # Round 3: the exchange is overlapped with the backward exactly as in the replicated mode (same events, same ranges), but
+    # every bucket is REDUCED TO THE RANK THAT OWNS ITS SHARD (dist.reduce) instead of all-reduced: each gradient element
+    # travels to one owner, which is what a reduce-scatter moves, without waiting for the whole arena.  Buckets never straddle
+    # a shard boundary.  (Round 2 issued one blocking reduce_scatter after the backward.)
+    def buckets(self, lo=0, hi=None):
+        n = self.model.arena().total if hi is None else hi
+        out, pos = [], lo
+        while pos < n:
+            end = min(n, pos + self.bucket_elems, (pos // self.shard + 1) * self.shard)
+            out.append((pos, end))
+            pos = end
+        return out[::-1]
 
-    def finish(self):
-        a = self.model.arena()
-        g = a.grad_full[:self.padded] if hasattr(a, "grad_full") else a.grad
-        from .engine import dw_join
-        if g.is_cuda:
-            dw_join()
-        mine = g[self.rank * self.shard:(self.rank + 1) * self.shard]
-        if self._nccl and g.numel() == self.padded:
-            dist.reduce_scatter_tensor(mine, g, op=dist.ReduceOp.SUM, group=self.group)       # in place: output = own slice of the input
-        else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)                        # gloo (tests): reduce everything, use the own shard
-        self._works, self._done, self._fired, self._armed = [], [], set(), True
+    def _exchange(self, t, b0, **kw):
+        return dist.reduce(t, dst=b0 // self.shard, op=dist.ReduceOp.SUM, group=self.group, **kw)
+
+    def _widen_back(self):
+        self._widen = [(b0, b1) for b0, b1 in self._widen if self.lo <= b0 < self.hi]      # only the own shard's sums are used
+        super()._widen_back()
 
     def optimizer_step(self, arena, lr4, wd4, step, max_norm, betas, eps):
         def sum_sq(t):

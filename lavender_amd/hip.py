@@ -368,6 +368,10 @@ def cast_bf16(src, dst, n):
     L.check(L.lib.lav_cast_f32_to_bf16(_s(), int(n), _p(src), _p(dst)), "lav_cast_f32_to_bf16")
 
 
+def widen_bf16(src, dst, n):
+    L.check(L.lib.lav_cast_bf16_to_f32(_s(), int(n), _p(src), _p(dst)), "lav_cast_bf16_to_f32")
+
+
 def fill_droppath(n_blocks, B, keep_prob, seed, out):
     L.check(L.lib.lav_fill_droppath(_s(), n_blocks, B, _p(keep_prob), int(seed) & 0xFFFFFFFF, _p(out)), "lav_fill_droppath")
 

@@ -78,7 +78,19 @@ def _worker(rank, world, port, q):
     except RuntimeError:
         pass
     red.finish()
-    q.put((rank, ok))
+    # half-precision exchange (grad_dtype="bf16"): buckets go through the bf16 staging arena, the sums come back widened; every
+    # rank holds the SAME values (replica equality), equal to the bf16-rounded inputs summed in bf16
+    arena.listeners.clear()
+    red16 = ArenaReducer(model, bucket_mb=0.05, grad_dtype="bf16")
+    red16.HALF_MIN_ELEMS = 1024
+    arena.grad.copy_(local)
+    red16.begin_step()
+    for f in arena.listeners:
+        f("fusion_grads_final")
+    red16.finish()
+    exp16 = sum(torch.randn(n, generator=torch.Generator().manual_seed(r)).bfloat16() for r in range(world)).float()
+    ok &= bool(torch.equal(arena.grad, exp16)) and bool(torch.allclose(arena.grad, expect, atol=0.05, rtol=0.02))
+    q.put((rank, ok, float(arena.grad.double().sum())))
     dist.destroy_process_group()
 
 
@@ -89,10 +101,11 @@ def test_arena_reducer_world2():
     ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()
-    res = [q.get(timeout=120) for _ in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
     for p in ps:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert [r[:2] for r in res] == [(0, True), (1, True)]
+    assert res[0][2] == res[1][2]                               # bf16 exchange: bit-identical gradients on both replicas
 
 
 # ---- ZeRO-1 (args.deepspeed): reduce-scatter + sharded AdamW + all-gather of the bf16 working copy ---------------------------
@@ -143,25 +156,34 @@ def _zero_worker(rank, world, port, q):
     total = 64 * 333                                            # not a multiple of world * 64: the last shard is short
     lr4, wd4 = [1e-2] * 4, [1e-3] * 4
     outs = {}
-    for kind in ("ddp", "zero1"):
+    for kind in ("ddp", "zero1", "zero1_bf16", "ddp_bf16"):
         arena = _MockArena(total, rank)
+        # two named ranges that straddle the shard boundary: the early exchange (reduce to the owning rank per bucket) must cut there
+        arena.names = ["trsfr.a", "enc_img.swin.layers.0.w"]
+        spans = {"trsfr.a": (64 * 10, 64 * 200), "enc_img.swin.layers.0.w": (64 * 200, 64 * 300)}
+        arena.span = lambda ns, sp=spans: (min(sp[x][0] for x in ns), max(sp[x][1] for x in ns))
         model = types.SimpleNamespace(arena=lambda a=arena: a)
-        red = (ZeroOneReducer if kind == "zero1" else ArenaReducer)(model)
+        red = (ZeroOneReducer if kind.startswith("zero1") else ArenaReducer)(model, grad_dtype="bf16" if kind.endswith("bf16") else "fp32")
+        red.HALF_MIN_ELEMS = 256
         for step in (1, 2):
             arena.grad_full.zero_()
             arena.grad.copy_(torch.randn(total, generator=torch.Generator().manual_seed(100 * step + rank)))
             red.begin_step()
             for f in arena.listeners:
-                f("fusion_grads_final")                         # ZeRO-1 ignores the overlap events
+                f("fusion_grads_final")                         # early exchange of the fusion-side range in both modes
+                f("swin_stage0_grads_final")
             red.finish()
             red.optimizer_step(arena, lr4, wd4, step, 1.0, (0.9, 0.98), 1e-8)
         red.gather_master()
         outs[kind] = (arena.master.clone(), arena.half.clone(), arena.m.numel(), arena.transposed_syncs)
+    (mb0, hb0, _, _), (mb1, hb1, _, _) = outs["ddp_bf16"], outs["zero1_bf16"]
+    ok16 = bool(torch.allclose(mb0, mb1, atol=1e-6)) and bool(torch.equal(hb0, hb1))   # bf16 exchange: ZeRO-1 == replicated as well
+    ok16 &= bool(torch.allclose(mb0, outs["ddp"][0], atol=2e-2))                        # and close to the fp32 exchange (Adam steps are +-lr)
     (m0, h0, n0, _), (m1, h1, n1, ts) = outs["ddp"], outs["zero1"]
     shard = ((total + world - 1) // world + 63) // 64 * 64
     ok = bool(torch.allclose(m0, m1, atol=1e-6)) and bool(torch.equal(h0, h1))      # ZeRO-1 == replicated AdamW
     ok &= n0 == total and n1 == min(shard, total - min(rank * shard, total)) and ts == 2   # optimizer state for the own shard only
-    q.put((rank, ok, float(m1.double().sum())))
+    q.put((rank, ok and ok16, float(m1.double().sum())))
     dist.destroy_process_group()
 
 

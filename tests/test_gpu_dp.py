@@ -31,7 +31,7 @@ def _rank_grads(rank, agent, m):
     return m.arena().grad.clone()
 
 
-def _worker(rank, world, port, q, zero=False):
+def _worker(rank, world, port, q, zero=False, bf16=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     torch.cuda.set_device(0)
@@ -41,8 +41,10 @@ def _worker(rank, world, port, q, zero=False):
     torch.manual_seed(100 + rank)                       # different initial weights: the broadcast must fix that
     m = LA.LAVENDER_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3), Tok()).cuda()
     m.arena()
-    agent = LA.Agent_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3, deepspeed=zero), m)
+    agent = LA.Agent_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3, deepspeed=zero, grad_comm_bf16=bf16), m)
     agent.prepare_dist_model()
+    assert agent.dp.grad_dtype == ("bf16" if bf16 else "fp32")
+    agent.dp.HALF_MIN_ELEMS = 4096                      # micro model: let its ranges take the half-precision path
     assert agent.dp is not None and agent.dp.world == world and agent.dp.zero_stage == (1 if zero else 0)
     w0 = m.arena().master.clone()
     # reference: both ranks' local gradients computed in this process with the reducer detached
@@ -72,11 +74,11 @@ def _worker(rank, world, port, q, zero=False):
     dist.destroy_process_group()
 
 
-def _run_two_ranks(zero):
+def _run_two_ranks(zero, bf16=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1000) + (37 if zero else 0)
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, zero)) for r in range(2)]
+    port = 29600 + (os.getpid() % 1000) + (37 if zero else 0) + (71 if bf16 else 0)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, zero, bf16)) for r in range(2)]
     for p in ps:
         p.start()
     import queue as _queue
@@ -113,6 +115,13 @@ def test_zero1_two_ranks_matches_replicated_step():
     w_ddp, s_ddp = _run_two_ranks(False)
     w_z, s_z = _run_two_ranks(True)
     assert abs(w_ddp - w_z) <= 1e-6 * max(1.0, abs(w_ddp)) and abs(s_ddp - s_z) <= 1e-6 * s_ddp, (w_ddp, w_z, s_ddp, s_z)
+
+
+def test_bf16_gradient_exchange_keeps_replicas_identical():
+    """args.grad_comm_bf16: gradient buckets cross the wire as bf16 (lav_cast_f32_to_bf16 / lav_cast_bf16_to_f32 on the comm
+    stream); the summed gradient is within bf16 rounding of the fp32 sum and both replicas (DDP and ZeRO-1) stay bit-identical."""
+    _run_two_ranks(False, bf16=True)
+    _run_two_ranks(True, bf16=True)
 
 
 def _rccl_worker(port, q):
