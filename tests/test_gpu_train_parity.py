@@ -210,6 +210,54 @@ def test_base_12l_backward_subset_vs_oracle():
     assert not bad, bad
 
 
+_SUBSET = ["fc_mtm.predictions.decoder.weight", "fc_mtm.predictions.transform.dense.weight", "trsfr.layer.11.output.dense.weight",
+           "trsfr.layer.6.attention.self.query.weight", "trsfr.layer.0.intermediate.dense.weight", "trsfr.layer.0.attention.output.LayerNorm.weight",
+           "enc_txt.emb_txt.word_embeddings.weight", "enc_img.emb_pos", "enc_img.fc.weight", "enc_img.swin.norm.weight",
+           "enc_img.swin.layers.3.blocks.1.mlp.fc2.weight", "enc_img.swin.layers.2.blocks.17.attn.qkv.weight",
+           "enc_img.swin.layers.2.blocks.9.attn.relative_position_bias_table", "enc_img.swin.layers.2.blocks.0.mlp.fc1.weight",
+           "enc_img.swin.layers.1.downsample.reduction.weight", "enc_img.swin.layers.1.blocks.1.attn.proj.weight",
+           "enc_img.swin.layers.0.blocks.0.norm1.weight", "enc_img.swin.patch_embed.proj.weight"]
+
+
+def _subset_report(m, P, names, rel_tol, cos_tol):
+    params, bad = dict(m.named_parameters()), []
+    for n in names:
+        a, b = params[n].grad.float().cpu(), P[n].grad
+        rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+        cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+        print(f"{n}: rel {rel:.4f} cos {cos:.5f} |g| {b.norm().item():.2e}")
+        if not (rel < rel_tol and cos > cos_tol):
+            bad.append((n, rel, cos))
+    return bad
+
+
+def test_base_12l_train_mode_b8_merged_pass_same_masks():
+    """The pass bench.py times, at width: Swin-B + 12 layers in .train() (dropout 0.1, drop-path 0.2), B = 8 so that the VTM side
+    has O = 4 negatives and the fusion encoder runs the MERGED batch of 8 + 32 = 40 sequences.  All masks of the HIP step are
+    rebuilt on the host and given to the oracle: both losses and a gradient of every kind along the depth must agree."""
+    from tests.helpers import build_filled_model
+    B = 8
+    R, P, batch, bc = _oracle_case("base", "b12l", B)
+    torch.set_num_threads(min(32, max(16, torch.get_num_threads())))
+    for v in P.values():
+        v.requires_grad_(True)
+    m = build_filled_model("base", "b12l", B).train()
+    m.arena()
+    out, logits, (l_mtm, l_vtm), masks = _train_step_with_recorded_masks(m, batch, B, bc)
+    assert out["out_vtm"].shape[0] == B * 4                        # O = 4: the merged 40-sequence pass
+    np.random.seed(88)
+    ref = R.pretrain_forward(P, batch, "base", bc["heads"], **masks)
+    r_mtm, r_vtm = R.pretrain_loss(ref)
+    (r_mtm + r_vtm).backward()
+    print("B=8 train-mode loss", l_mtm, l_vtm, "oracle (same masks)", r_mtm.item(), r_vtm.item())
+    assert abs(l_mtm - r_mtm.item()) < 1e-2 and abs(l_vtm - r_vtm.item()) < 1e-2
+    for key in ("out_mtm", "out_vtm"):
+        d = (logits[key] - ref[key].detach()).abs()
+        print(key, "train-mode logits max", d.max().item(), "mean", d.mean().item())
+        assert d.max() < 4e-2 and d.mean() < 5e-3
+    assert not _subset_report(m, P, _SUBSET, rel_tol=0.04, cos_tol=0.999)          # measured worst 2.4 % (a relative_position_bias_table)
+
+
 def test_cfg4_swin_large_384_real_widths_forward_vs_oracle():
     """BASELINE config 4 at its real widths: Swin-L (E=192, heads 6..48, C up to 1536), 5x384^2 frames, (5,12,12) windows of
     720 tokens, 757-token fusion sequences, 12 layers; batch 2 forward + losses against the oracle."""
@@ -246,6 +294,26 @@ def test_cfg4_swin_large_384_real_widths_forward_vs_oracle():
         # 64 / 128 positions only: the floor is 0.93 and every disagreement must be a near-tie of the oracle itself
         assert d.max() < 3e-2 and d.mean() < 5e-3 and agree >= 0.93 and margin < 3e-2
     assert abs(ls_mtm.item() - l1.item()) < 1e-2 and abs(ls_vtm.item() - l2.item()) < 1e-2
+    # backward at these widths (the generic 720-token window kernels incl. their bias-table gradient, 757-token sequences), B = 1
+    b1 = {k: v[:1] for k, v in batch.items()}
+    for v in P.values():
+        v.requires_grad_(True)
+    np.random.seed(88)
+    ref = R.pretrain_forward(P, b1, "large", bc["heads"])
+    r1, r2 = R.pretrain_loss(ref)
+    (r1 + r2).backward()
+    m.arena().zero_grad()
+    np.random.seed(88)
+    out = m({k: v.cuda() for k, v in b1.items()})
+    ls = lf(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten()) + lf(out["out_vtm"].flatten(0, 1), out["ans_vtm"].flatten(), count=out["ans_vtm"].shape[0])
+    ls.backward()
+    torch.cuda.synchronize()
+    assert abs(ls.item() - (r1 + r2).item()) < 1e-2
+    names = ["trsfr.layer.11.output.dense.weight", "trsfr.layer.0.attention.self.query.weight", "enc_img.fc.weight",
+             "enc_img.swin.layers.2.blocks.9.attn.relative_position_bias_table", "enc_img.swin.layers.2.blocks.17.attn.qkv.weight",
+             "enc_img.swin.layers.0.blocks.1.attn.relative_position_bias_table", "enc_img.swin.layers.1.blocks.0.attn.proj.weight",
+             "enc_img.swin.layers.3.blocks.1.mlp.fc2.weight", "enc_img.swin.patch_embed.proj.weight"]
+    assert not _subset_report(m, P, names, rel_tol=0.04, cos_tol=0.999)          # measured worst 2.4 % (a relative_position_bias_table)
 
 
 def test_cfg5_retrieval_swin_base_width_vs_oracle():
@@ -261,9 +329,12 @@ def test_cfg5_retrieval_swin_base_width_vs_oracle():
     batch = make_batch(B, X=X, vocab=bc["vocab"])
     batch["vid"] = [0, 1, 1, 3]
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    with torch.no_grad():
-        ref, ans = R.retrieval_forward(P, batch, "base", bc["heads"])
-        lref = torch.nn.functional.cross_entropy(ref.reshape(-1, ref.shape[-1]), ans.reshape(-1), ignore_index=-1)
+    for v in P.values():
+        v.requires_grad_(True)
+    ref, ans = R.retrieval_forward(P, batch, "base", bc["heads"])
+    lref = torch.nn.functional.cross_entropy(ref.reshape(-1, ref.shape[-1]), ans.reshape(-1), ignore_index=-1)
+    lref.backward()
+    ref, lref = ref.detach(), lref.detach()
     m = LAVENDER_Retrieval_MLM(make_args("base", "b12l", B), Tok())
     sd = m.state_dict()
     new = {k: R.fill_tensor(k, v.shape) for k, v in sd.items() if v.is_floating_point()}
@@ -271,13 +342,19 @@ def test_cfg5_retrieval_swin_base_width_vs_oracle():
     m.load_state_dict(new, strict=False)
     m.cuda().eval()
     m.arena()
-    with torch.no_grad():
-        out, lab = m({"img": batch["img"].cuda(), "txt": batch["txt"].cuda(), "mask": batch["mask"].cuda(), "vid": batch["vid"]})
-        ls = CrossEntropyIgnore()(out.flatten(0, 1), lab.flatten())
+    m.arena().zero_grad()
+    out, lab = m({"img": batch["img"].cuda(), "txt": batch["txt"].cuda(), "mask": batch["mask"].cuda(), "vid": batch["vid"]})
+    a = out.detach().float().cpu()
+    ls = CrossEntropyIgnore()(out.flatten(0, 1), lab.flatten())
+    ls.backward()
+    torch.cuda.synchronize()
     assert (lab.cpu() == ans).all()
-    a, b = out.float().cpu(), ref
+    b = ref
     d = (a - b).abs()
     agree = (a.argmax(-1) == b.argmax(-1)).float().mean().item()
     print("cfg5 logits max", d.max().item(), "mean", d.mean().item(), "argmax agree", agree, "loss", ls.item(), lref.item())
     assert d.max() < 3e-2 and d.mean() < 5e-3 and agree >= 0.97
     assert abs(ls.item() - lref.item()) < 1e-2
+    # and the gradients of the B x B pass at this width (one tensor of every kind along the depth)
+    names = [n for n in _SUBSET if not n.startswith("enc_txt.emb_txt.word_embeddings")] + ["enc_txt.emb_txt.position_embeddings.weight"]
+    assert not _subset_report(m, P, names, rel_tol=0.04, cos_tol=0.999)          # measured worst 2.4 % (a relative_position_bias_table)
