@@ -528,8 +528,11 @@ __global__ __launch_bounds__(512) void win_dkv3(AttnArgs a, int bsplit, const fl
 // ------------------------------------------------------------------------------------------------------
 // relative-position-bias gradient: dtable[code(q) - code(k) + const, head] += sum over windows and batch of dS[q, k].
 // Workgroup = (head, window position, query half, batch slice); wave = (query strip qs of the half, key half kh): 4 key tiles,
-// 64 accumulators fed by one-hot MFMAs (dsa += E . dS: no VALU work), flushed once per workgroup through LDS float atomics.
-// LDS: [2][K 16 KB | V 16 KB | Q half 8 KB | dO half 8 KB | lse 1 KB | -delta 1 KB] + table + codes + token rows.
+// 64 accumulators fed by one-hot MFMAs (dsa += E . dS: no VALU work).  Flush, once per workgroup: the accumulators are written
+// as a dense [128 queries][256 keys] fp32 matrix over the (then idle) operand buffers and every thread sums the entries of a few
+// offset classes by walking the box of queries that has a partner key at that offset -- each (q, k) pair is read exactly once,
+// no LDS atomics (the ds_add_f32 flush took 45 of the kernel's 99 us on the stage-2 shape), one global atomic per class.
+// LDS: [2][K 16 KB | V 16 KB | Q half 8 KB | dO half 8 KB | lse 1 KB | -delta 1 KB] (>= 128 x 257 floats for the flush) + token rows.
 // ------------------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(512) void win_dbias3(AttnArgs a, int bsplit, const float* ndelta_in) {
@@ -538,21 +541,18 @@ __global__ __launch_bounds__(512) void win_dbias3(AttnArgs a, int bsplit, const 
     const int qh = blockIdx.x & 1;
     if (!win_geo(a, bsplit, blockIdx.x >> 1, g)) return;
     constexpr int BUF = 32768 + 16384 + 2048;
-    float* dtbl = (float*)(smem + 2 * BUF);
-    int* kcode = (int*)(dtbl + a.tbl_rows);
-    int* srel_l = kcode + 256;
+    constexpr int DLD = 257;                                 // row stride of the flush matrix (floats): lanes = consecutive queries
+    constexpr int MAIN = 2 * BUF > 128 * DLD * 4 ? 2 * BUF : 128 * DLD * 4;
+    int* srel_l = (int*)(smem + MAIN);
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qs = wave & 3, kh = wave >> 2;
     const int qt = qh * 4 + qs;
     const int N = a.N, C = a.C, ld = 3 * C;
     const float sc = a.d.scale * LOG2E;
-    for (int r = tid; r < a.tbl_rows; r += 512) dtbl[r] = 0.f;
     if (tid < 256) {
-        const int i = tid;
-        kcode[i] = i < N ? (i / (a.d.cfg_ww * a.d.cfg_wh)) * a.cstride_d + ((i / a.d.cfg_ww) % a.d.cfg_wh) * a.cstride_h + (i % a.d.cfg_ww) : 0;
-        const int rel = a.d.tok_table[g.ws * 256 + i];
-        srel_l[i] = rel < 0 ? 0 : rel;
+        const int rel = a.d.tok_table[g.ws * 256 + tid];
+        srel_l[tid] = rel < 0 ? 0 : rel;
     }
     const int q = qt * 32 + j;
     const bool q_ok = q < N;
@@ -656,9 +656,9 @@ __global__ __launch_bounds__(512) void win_dbias3(AttnArgs a, int bsplit, const 
         dma_wait_all();
         __syncthreads();
     }
-    // ---- flush: accumulators -> LDS table (index = code(q) - code(k) + const) -> one global atomic per table row ------------
+    // ---- flush (see the header): dense matrix, then per-class box sums ------------------------------------------------------
+    float* Dm = (float*)smem;                                // the loop's last barrier has passed: the operand buffers are idle
     if (strip_on && q_ok) {
-        const int qc = kcode[q] + a.tbl_const;
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
             const int t = kh * 4 + i;
@@ -666,14 +666,38 @@ __global__ __launch_bounds__(512) void win_dbias3(AttnArgs a, int bsplit, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = t * 32 + tile_row(r, hi);
-                if (k < N) atomicAdd(&dtbl[qc - kcode[k]], dsa[i][r]);
+                if (k < N) Dm[(qs * 32 + j) * DLD + k] = dsa[i][r];
             }
         }
     }
     __syncthreads();
-    for (int r = tid; r < a.tbl_rows; r += 512) {
-        const float v = dtbl[r];
-        if (v != 0.f) atomicAdd(a.dbias + (long)r * a.d.heads + g.head, v);
+    // token index i < N  <->  (d, h, w) with the CONFIGURED (h, w) extents (relative_position_index[:N, :N], video_swin.py:153)
+    const int ch = a.d.cfg_wh, cw = a.d.cfg_ww, chw = ch * cw;
+    const int dv = (N + chw - 1) / chw;
+    const int nw_ = 2 * cw - 1, nh_ = 2 * ch - 1;
+    const int ncls = (2 * dv - 1) * nh_ * nw_;
+    const int q_lo = qh * 128;
+    for (int c = tid; c < ncls; c += 512) {
+        const int dw = c % nw_ - (cw - 1), dh = (c / nw_) % nh_ - (ch - 1), dd = c / (nw_ * nh_) - (dv - 1);   // offset = q - k
+        const int koff = dd * chw + dh * cw + dw;
+        float part[4] = {0.f, 0.f, 0.f, 0.f};                // independent partial sums: the LDS reads of a row pipeline
+        const int w0 = max(0, dw), w1 = min(cw, cw + dw);
+        for (int qd = max(0, dd); qd < min(dv, dv + dd); ++qd)
+            for (int qhh = max(0, dh); qhh < min(ch, ch + dh); ++qhh) {
+                const int qrow = (qd * ch + qhh) * cw;
+                if (qrow + w1 <= q_lo || qrow + w0 >= q_lo + 128) continue;      // row outside this query half
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {                // configured window widths up to 8 (Swin: 7); wider ones loop below
+                    const int qq = qrow + w0 + u, ql = qq - q_lo;
+                    if (w0 + u < w1 && (unsigned)ql < 128u && qq < N && qq - koff < N) part[u & 3] += Dm[ql * DLD + (qq - koff)];
+                }
+                for (int qw = w0 + 8; qw < w1; ++qw) {
+                    const int qq = qrow + qw, ql = qq - q_lo;
+                    if ((unsigned)ql < 128u && qq < N && qq - koff < N) part[0] += Dm[ql * DLD + (qq - koff)];
+                }
+            }
+        const float sum = (part[0] + part[1]) + (part[2] + part[3]);
+        if (sum != 0.f) atomicAdd(a.dbias + (long)(dd * a.cstride_d + dh * a.cstride_h + dw + a.tbl_const) * a.d.heads + g.head, sum);
     }
 }
 
@@ -756,7 +780,7 @@ int win_persistent_fwd(void* stream, const AttnArgs& a) {
 int win_persistent_dbias(void* stream, const AttnArgs& a, const float* ndelta) {
     const int bs = pick_bsplit(a, 2);
     const dim3 grid(a.d.heads * a.nWs * bs * 2);
-    const size_t lds = 2 * (32768 + 16384 + 2048) + (size_t)a.tbl_rows * 4 + 2048;
+    const size_t lds = 128 * 257 * 4 + 1024;                 // max(two operand buffers, the flush matrix) + token rows
 #define DB3_(NT) { big_lds(win_dbias3<NT>, lds); hipLaunchKernelGGL(win_dbias3<NT>, grid, dim3(512), lds, (hipStream_t)stream, a, bs, ndelta); }
     NT_SWITCH((a.N + 31) / 32, DB3_)
 #undef DB3_
