@@ -82,6 +82,24 @@ class EncTxt(nn.Module):
         return E.TextEmbedFn.apply(arena.anchor, txt, self.emb_txt, p)
 
 
+class _AttentionsNotMaterialised:
+    """Second return value of go_cross / go_cross_pairs.  The reference asks the HF encoder for output_attentions=True
+    (model.py:242-243) and every pre-training / retrieval / QA caller drops them; the fused attention kernels never write the
+    (n, heads, L, L) probabilities (19 MB per layer at the benchmark batch, 12 layers).  A caller that does USE them gets a clear
+    error instead of a silent None."""
+
+    def _fail(self, *a, **k):
+        raise NotImplementedError("go_cross: attention probabilities are not materialised by the fused MI355X attention kernels "
+                                  "(model.py:242-243 returns them; no caller on the pre-training path reads them)")
+    __getitem__ = __iter__ = __len__ = __bool__ = _fail
+
+    def __repr__(self):
+        return "<attentions: not materialised>"
+
+
+_NO_ATTN = _AttentionsNotMaterialised()
+
+
 class LAVENDER_Base(nn.Module):
     """model.py:145-473 (hot-path methods + checkpoint contract)."""
 
@@ -201,10 +219,10 @@ class LAVENDER_Base(nn.Module):
         if attn_mask_type == "seq2seq":
             # (B, L, L) mask of get_attn_mask in kernel form: video keys by mask_img, text keys all valid but causal
             key_mask = torch.cat([mask_img, torch.ones_like(mask_txt)], dim=1)
-            return self._encode(feat, key_mask, causal_from=mask_img.shape[1]), None
+            return self._encode(feat, key_mask, causal_from=mask_img.shape[1]), _NO_ATTN
         mask = self.get_attn_mask(mask_img, mask_txt, attn_mask_type=attn_mask_type)
         assert feat.shape[1] == mask.shape[1], f"mask and feat must have the same length, got {feat.shape[1]} vs. {mask.shape[1]}"
-        return self._encode(feat, mask), None
+        return self._encode(feat, mask), _NO_ATTN
 
     def go_cross_pairs(self, feat_img, mask_img, feat_txt, mask_txt, vi, ti):
         """go_cross on the pair list (video vi[k], text ti[k]) without materialising per-pair copies in Python
@@ -213,7 +231,7 @@ class LAVENDER_Base(nn.Module):
         vi_t = torch.as_tensor(np.asarray(vi), device=mask_img.device)
         ti_t = torch.as_tensor(np.asarray(ti), device=mask_img.device)
         mask = torch.cat([mask_img[vi_t], mask_txt[ti_t]], dim=1)
-        return self._encode(feat, mask), None
+        return self._encode(feat, mask), _NO_ATTN
 
     def prepro_txt_inputs(self, txt, mask_txt, feat_txt, task_name=None, prompt=None):
         """model.py:292-307 with enable_task_token / enable_prompt off (the shipped pretrain config): identity."""
