@@ -164,17 +164,23 @@ __global__ __launch_bounds__(512) void win_fwd3(AttnArgs a, int bsplit) {
         // under the VALU chain of the same wave.  Online softmax with an exact conditional rescale (wave-uniform branch, rare
         // after the first tiles).
         f32x16 sa, sb;
-        auto qk = [&](int t, f32x16& s) {
+        // LDS fragments are fetched one step ahead of the MFMAs that consume them (K of tile t+1 while tile t's S is issued, V of
+        // tile t at the top of its softmax): the ds_read latency sits under matrix / VALU work instead of in front of it
+        bf16x8 ka[2], kb[2];
+        auto kload = [&](int t, bf16x8 (&k)[2]) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) k[ks] = *(const bf16x8*)(Ks + krow_off<HD>(t * 32 + j, ks * 2 + hi));
+        };
+        auto qk = [&](int t, f32x16& s, const bf16x8 (&kc)[2], bf16x8 (&kn)[2]) {
+            if (t + 1 < NT) kload(t + 1, kn);
             const f32x16 z = ZERO16;
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[t][0].b, id0, z, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[t][1].b, id1, s, 0, 0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 kf = *(const bf16x8*)(Ks + krow_off<HD>(t * 32 + j, ks * 2 + hi));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-            }
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[0], qf[0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[1], qf[1], s, 0, 0, 0);
         };
         auto soft = [&](int t, const f32x16& s) {
+            const bf16x8 vf0 = tr_frag_k32(Vs, t * 32, lane), vf1 = tr_frag_k32(Vs, t * 32 + 16, lane);
             float mx = max3f(s[0], s[1], s[2]);
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mx = max3f(mx, s[r], s[r + 1]);
@@ -195,18 +201,18 @@ __global__ __launch_bounds__(512) void win_fwd3(AttnArgs a, int bsplit) {
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
                 Frag pf; pf.u = make_uint4(pk[4 * sl], pk[4 * sl + 1], pk[4 * sl + 2], pk[4 * sl + 3]);
-                bf16x8 vf = tr_frag_k32(Vs, t * 32 + 16 * sl, lane);
-                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.b, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl ? vf1 : vf0, pf.b, o, 0, 0, 0);
                 lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones0, pf.b, lacc, 0, 0, 0);
             }
         };
-        qk(0, sa);
+        kload(0, ka);
+        qk(0, sa, ka, kb);
 #pragma unroll
         for (int t = 0; t < NT; t += 2) {
-            if (t + 1 < NT) qk(t + 1, sb);
+            if (t + 1 < NT) qk(t + 1, sb, kb, ka);
             soft(t, sa);
             if (t + 1 < NT) {
-                if (t + 2 < NT) qk(t + 2, sa);
+                if (t + 2 < NT) qk(t + 2, sa, ka, kb);
                 soft(t + 1, sb);
             }
         }
