@@ -352,7 +352,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")) as fh:
                 pm = json.load(fh)
             if a.workload == "cfg2" and B == 32 and a.layers == 12 and a.size == "base":
                 traffic = pm["hbm_bytes_per_launch"]
@@ -363,10 +363,10 @@ def main():
         for lay_i, fl_i, e0_i, e1_i, _nb_i in rec_iso:
             if lay_i == 0:
                 iso[0] += 1; iso[1] += fl_i; iso[2] += e0_i.elapsed_time(e1_i) * 1e-3
-        roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T and input-gradient dy.(W^T)^T GEMMs: gemm_huge/big/gemm_kernel<NT>)",
+        roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T and input-gradient dy.(W^T)^T GEMMs: gemm_huge / gemm_h192 / gemm_big / gemm_kernel<NT>)",
                 "achieved": round(fl / tm / 1e12, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tm / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_hbm_traffic.md)",
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_pmc_hbm_traffic.md)",
                 "algorithmic_bytes_per_launch": round(nb / n),
                 "launches_per_step": n, "avg_launch_us": round(tm / n * 1e6, 2), "avg_launch_gflop": round(fl / n / 1e9, 3),
                 "note": "achieved / avg_launch_us are measured in the shipped configuration, where weight-gradient GEMMs of a second "
@@ -399,7 +399,9 @@ def main():
                        "replicated rows) read from a TSV, decoded / resized / cropped on the GPU, host masking, per step",
                "config": {"workload": f"{what_dp}{what}Swin-{a.size}-K600-22k + {a.layers}-layer fusion + MLM head, "
                                       f"{'main_retrieval_mlm' if retrieval else 'main_pretrain_mlm'} path, "
-                                      f"fwd+bwd+clip+AdamW, dropout 0.1 / drop-path 0.2 on",
+                                      f"fwd+bwd+clip+AdamW, dropout 0.1 / drop-path 0.2 on; "
+                                      + ("inputs resident in HBM, labels prebuilt: host masking() + H2D copy are outside the timed region"
+                                         if a.input == "resident" else "input pipeline + host masking() inside the timed region"),
                           "per_gpu_batch": B, "global_batch": B * world, "frames": T, "size_img": S, "size_txt": X,
                           "parallelism": f"dp{world}", "params_M": round(nparam / 1e6, 2),
                           "algorithmic_tflop_per_step_per_gpu": round(fstep * B / 1e12, 2),
