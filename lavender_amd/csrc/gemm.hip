@@ -768,18 +768,22 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
 // RF = 16-row fragments per wave: 8 -> 256-row tiles; 6 -> 192-row tiles (K-contiguous layouts with a specialised epilogue only):
 // a 45120 x 768 output is 531 tiles of 256 x 256 = 2.07 rounds on 256 CUs (a third of the last round's CUs idle for a whole
 // tile), but 705 tiles of 192 x 256 = 2.75 rounds of 3/4-size tiles.
-template <bool AKC, bool BKC, unsigned F, int NW, int RF = 8>
+template <bool AKC, bool BKC, unsigned F, int NW, int RF = 8, int BNT = 256>
 __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
     constexpr int BMT = 2 * RF * 16;                      // tile rows
     constexpr int IPA = BMT / 8 / NW;                     // direct-to-LDS wave-instructions per A tile per wave (K-contiguous A)
-    static_assert(RF == 8 || (AKC && F != EF_ALL && F != EF_TNFLUSH && NW == 8), "192-row tiles: K-contiguous A, specialised epilogue");
+    static_assert(RF == 8 || (AKC && F != EF_ALL && F != EF_TNFLUSH), "192-row tiles: K-contiguous A, specialised epilogue");
+    static_assert(BNT == 256 || (AKC && BKC && NW == 4 && F != EF_ALL && F != EF_TNFLUSH), "128-column tiles: 4 waves, both operands K-contiguous");
     constexpr int WN = NW / 2;                            // wave grid 2 (m) x WN (n)
-    constexpr int NJ = 16 / WN;                           // 16-column fragments per wave
+    constexpr int NJ = BNT / 16 / WN;                     // 16-column fragments per wave
     constexpr int IPW = 32 / NW;                          // direct-to-LDS wave-instructions per operand tile per wave
+    constexpr int IPB = BNT / 8 / NW;                     // ... per K-contiguous B tile per wave
+    constexpr int BOFF = BNT == 256 ? 32768 : BMT * 128;  // B tile behind the A tile
+    constexpr int STAGE = BNT == 256 ? HUGE_STAGE : (BMT + BNT) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tiles_n = g.N / 256, tiles_m = (g.M + BMT - 1) / BMT;
+    const int tiles_n = g.N / BNT, tiles_m = (g.M + BMT - 1) / BMT;
     const int nwg = tiles_m * tiles_n;
     // 1-D grid of nwg * splits blocks; hardware block b runs on XCD b % 8.  The bijective remap gives each XCD one
     // contiguous run of (split, tile) work items, split-major: blocks that share a k-range (and so the same rows of both
@@ -799,7 +803,7 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
         const int gw = min(g.group_n, tiles_n - cg * g.group_n);          // last group may be narrower
         tm = rem / gw; tn = cg * g.group_n + rem % gw;
     }
-    const int m0 = tm * BMT, n0 = tn * 256;
+    const int m0 = tm * BMT, n0 = tn * BNT;
     const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nk = (kend - kbeg) / BKT;
@@ -820,20 +824,20 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
     }
 
     auto issue = [&](int kt) {
-        char* st = smem + (kt & 1) * HUGE_STAGE;
+        char* st = smem + (kt & 1) * STAGE;
         const int k0 = kbeg + kt * BKT;
         if (AKC) big_glds<true, IPA>(st, g.A, g.lda, m0, g.M, k0, wave, lane);
         else huge_glds_strided<IPW>(st, g.A, g.lda, m0, g.M, k0, wave, lane);
-        if (BKC) big_glds<true, IPW>(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);
-        else huge_glds_strided<IPW>(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);
+        if (BKC) big_glds<true, IPB>(st + BOFF, g.B, g.ldb, n0, g.N, k0, wave, lane);
+        else huge_glds_strided<IPW>(st + BOFF, g.B, g.ldb, n0, g.N, k0, wave, lane);
     };
     if (nk > 0) issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     for (int kt = 0; kt < ((g.dbg & 2) ? 0 : nk); ++kt) {
-        const char* la = smem + (kt & 1) * HUGE_STAGE;
-        const char* lb = la + 32768;
+        const char* la = smem + (kt & 1) * STAGE;
+        const char* lb = la + BOFF;
         if (kt + 1 < nk) issue(kt + 1);
         int kmode = 1;
         if (!AKC && g.e.k_keep) {
@@ -876,7 +880,7 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
     }
 
     if (g.dbg & 1) return;
-    if constexpr (NW == 8 && F != EF_ALL && F != EF_TNFLUSH) {
+    if constexpr ((NW == 8 || BNT == 128) && F != EF_ALL && F != EF_TNFLUSH) {
         // specialised forward / input-gradient epilogues: every wave stages its own accumulator block through a private LDS slice
         // in 64- or 32-row chunks and stores it in full 128-byte row pieces -- no block barriers.  Round 3 tried the epilogue straight
         // from the accumulator registers (swapped MFMA operands + permuted B rows so that a lane holds row-contiguous columns, no LDS
@@ -930,6 +934,15 @@ template <bool AKC, bool BKC, unsigned F = EF_ALL>
 __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 8>(g); }
 template <bool AKC, bool BKC, unsigned F>
 __global__ __launch_bounds__(512) void gemm_h192_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 8, 6>(g); }
+// 192 x 128 tiles on FOUR waves (2 x 2 of 96 x 64, the h192 wave tile) with 2 x 40 KB of stages: TWO workgroups fit a CU (LDS 2 x 80 KB,
+// 162 VGPRs, 2 waves per SIMD), so one workgroup's epilogue (HBM-bound, matrix pipe idle) runs under the other's k-loop.  Round-3
+// experiment, NOT selected by default (LAV_GEMM_Q=1 forces it, 9 = long-K narrow outputs only; tools/q_probe.py): bit-identical results;
+// isolated it wins 4-5 % on 45120 x 768 x {2304, 3072} and loses 0-34 % everywhere else (the tile moves 1.63x the operand bytes per flop
+// through L2 -> LDS and reads 10 fragments per 24 MFMAs instead of 12 per 32); the step goes 77.9 -> 80.5 ms with it everywhere and
+// stays where it is with it on the two shapes it wins.  Co-resident workgroups do hide the epilogue; the smaller tile costs more.
+#define Q_LDS 81920
+template <bool AKC, bool BKC, unsigned F>
+__global__ __launch_bounds__(256, 2) void gemm_q_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 4, 6, 128>(g); }
 
 // ------------------------------------------------------------------------------------------------------
 // Ping-pong 256x256x32 kernels.  8 waves in two groups of four -- group g = wave >> 2 owns rows [128 g, 128 g + 128) of
@@ -1396,6 +1409,7 @@ static bool lav_gemm_pp_tn = getenv("LAV_GEMM_PP_TN") ? atoi(getenv("LAV_GEMM_PP
 // 45120 x 3072 x 768 GEMMs and on 8192^3, nothing on narrower outputs).  LAV_GEMM_GROUP_N=0 restores n-fastest, other values force G.
 static int lav_gemm_group_n = getenv("LAV_GEMM_GROUP_N") ? atoi(getenv("LAV_GEMM_GROUP_N")) : -1;
 static int lav_gemm_h192 = getenv("LAV_GEMM_H192") ? atoi(getenv("LAV_GEMM_H192")) : 1;          // 192-row tiles for outputs that under-fill the last round of 256-row tiles
+static int lav_gemm_q = getenv("LAV_GEMM_Q") ? atoi(getenv("LAV_GEMM_Q")) : 0;                                     // 192x128 four-wave tiles, two workgroups per CU
 static int lav_gemm_dbg = getenv("LAV_GEMM_DBG") ? atoi(getenv("LAV_GEMM_DBG")) : 0;                               // probe hook: GemmArgs.dbg of the 256x256 kernel
 static int lav_gemm_pp_dbg = 0;                            // ablation builds of the ping-pong kernel (probe only, wrong results): 1 no refills, 2 no fragment reads, 4 no MFMAs
 extern "C" int lav_gemm_select(int which, int value) {    // probe hook (within-process A/B): which 0 = ping-pong kernel on/off; returns the old value
@@ -1406,6 +1420,7 @@ extern "C" int lav_gemm_select(int which, int value) {    // probe hook (within-
     if (which == 5) { old = lav_gemm_dbg; lav_gemm_dbg = value; }
     if (which == 6) { old = lav_gemm_group_n; lav_gemm_group_n = value; }
     if (which == 7) { old = lav_gemm_h192; lav_gemm_h192 = value; }
+    if (which == 8) { old = lav_gemm_q; lav_gemm_q = value; }
     return old;
 }
 
@@ -1464,8 +1479,8 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
                        S_BDR = EF_BIAS | EF_DROP | EF_RSCALE | EF_RES, S_BDRO = S_BDR | EF_O32;
     const unsigned fsel = !(fm & ~S_B) ? S_B : !(fm & ~S_BG) ? S_BG : !(fm & ~S_GC) ? S_GC : !(fm & ~S_BDR) ? S_BDR :
                           ((fm & EF_O32) && !(fm & ~S_BDRO)) ? S_BDRO : EF_ALL;
-    constexpr int lav_threads_gemm_huge_kernel = 512, lav_threads_gemm_big_kernel = 512, lav_threads_gemm_h192_kernel = 512;
-    (void)lav_threads_gemm_huge_kernel; (void)lav_threads_gemm_big_kernel; (void)lav_threads_gemm_h192_kernel;
+    constexpr int lav_threads_gemm_huge_kernel = 512, lav_threads_gemm_big_kernel = 512, lav_threads_gemm_h192_kernel = 512, lav_threads_gemm_q_kernel = 256;
+    (void)lav_threads_gemm_huge_kernel; (void)lav_threads_gemm_big_kernel; (void)lav_threads_gemm_h192_kernel; (void)lav_threads_gemm_q_kernel;
 #define LAV_LAUNCH_ONE(KERN, AKC_, BKC_, F_, GRID, LDS)                                                                   \
     do {                                                                                                                  \
         static bool attr_done = false;                                                                                    \
@@ -1519,6 +1534,18 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     // 192-row tiles where they fill the machine better (narrow outputs: N = 768 at M = 45120 is 2.07 rounds of 256-row tiles)
     const long t_h192 = (long)((M + 191) / 192) * (N / 256);
     const double f_h192 = ((N % 256) == 0 && fsel != EF_ALL && lav_gemm_h192) ? fill(t_h192, 256, 0.97) : 0.0;
+    if (big && lav_gemm_q && layout == 0 && fsel != EF_ALL && (N % 128) == 0 && (lav_gemm_q != 9 || (N <= 768 && K >= 2048 && M >= 16384))) {
+        g.k_per_split = K;
+        g.dbg = lav_gemm_dbg;
+        const int tn_ = N / 128;
+        g.group_n = lav_gemm_group_n >= 0 ? lav_gemm_group_n : (lav_gemm_q >= 2 && lav_gemm_q != 9 && tn_ >= lav_gemm_q ? lav_gemm_q : 0);
+        dim3 qgrid((unsigned)((long)((M + 191) / 192) * tn_));
+#define LAV_Q(F_) LAV_LAUNCH_ONE(gemm_q_kernel, true, true, F_, qgrid, Q_LDS);
+        if (fsel == S_B) LAV_Q(S_B) else if (fsel == S_BG) LAV_Q(S_BG) else if (fsel == S_GC) LAV_Q(S_GC)
+        else if (fsel == S_BDR) LAV_Q(S_BDR) else LAV_Q(S_BDRO)
+#undef LAV_Q
+        return lav_check_launch("lav_gemm_bf16");
+    }
     if (big && !lav_gemm_no_huge && f_h192 > f_huge + 0.02 && f_h192 >= f_big && f_h192 >= f_small) {
         g.k_per_split = K;
         g.dbg = lav_gemm_dbg; g.group_n = 0;
