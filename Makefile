@@ -2,7 +2,7 @@
 HIPCC ?= hipcc
 ARCH  ?= gfx950
 CSRC  := lavender_amd/csrc
-OBJS  := $(CSRC)/gemm.o $(CSRC)/layernorm.o $(CSRC)/attention.o $(CSRC)/attention_win.o $(CSRC)/attention_seq.o $(CSRC)/embed.o $(CSRC)/loss_optim.o $(CSRC)/validate.o $(CSRC)/pipeline.o $(CSRC)/runtime.o
+OBJS  := $(CSRC)/gemm.o $(CSRC)/layernorm.o $(CSRC)/attention.o $(CSRC)/attention_win.o $(CSRC)/attention_seq.o $(CSRC)/attention_winl.o $(CSRC)/embed.o $(CSRC)/loss_optim.o $(CSRC)/validate.o $(CSRC)/pipeline.o $(CSRC)/runtime.o
 LIB   := lavender_amd/liblavender_hip.so
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value -munsafe-fp-atomics
 

@@ -179,12 +179,15 @@ int lav_attention_fwd(void* stream, const lav_attn_desc* d, const void* qkv, voi
 /* dqkv: bf16 same layout as qkv (fully written).  dbias_table: fp32, atomically accumulated (window mode). */
 int lav_attention_bwd(void* stream, const lav_attn_desc* d, const void* qkv, const void* out, const void* dout,
                       const float* lse, void* dqkv, float* dbias_table);
-/* Window mode, N <= 256 with the precomputed tables: the bias-table gradient ALONE.  Call lav_attention_bwd with
- * dbias_table = NULL first (it leaves -delta behind the lse in the lse buffer), then this on any stream ordered after it --
+/* Window mode, N <= 256 with the precomputed tables or 256 < N <= 768 (lav_attention_bias_split(d) == 1): the bias-table gradient
+ * ALONE.  Call lav_attention_bwd with dbias_table = NULL first (it leaves delta behind the lse in the lse buffer), then this on any stream ordered after it --
  * the table gradient is a parameter gradient and does not have to sit in the dy -> dx chain (the reference computes it inside
  * autograd of video_swin.py:153-160). */
 int lav_attention_bwd_bias(void* stream, const lav_attn_desc* d, const void* qkv, const void* dout, const float* lse,
                            float* dbias_table);
+/* 1 when the bias-table gradient of this descriptor can run as its own launch (lav_attention_bwd_bias), 0 when
+ * lav_attention_bwd has to produce it (sequence mode has none; windows of more than 768 tokens use the generic kernels). */
+int lav_attention_bias_split(const lav_attn_desc* d);
 size_t lav_attention_lse_elems(const lav_attn_desc* d);
 /* Fills d->comb and d->combT (each n_types*heads*8*8*64*16 bf16) from the current bias table: value(q,k) =
  * table[index(q,k), head] + (region(q) != region(k) ? -100 : 0), -30000 for padded keys (video_swin.py:153-160). */

@@ -67,6 +67,7 @@ _SIGS = {
     "lav_attention_fwd": (i32, [vp, P(AttnDesc), vp, vp, vp]),
     "lav_attention_bwd": (i32, [vp, P(AttnDesc), vp, vp, vp, vp, vp, vp]),
     "lav_attention_bwd_bias": (i32, [vp, P(AttnDesc), vp, vp, vp, vp]),
+    "lav_attention_bias_split": (i32, [P(AttnDesc)]),
     "lav_attention_lse_elems": (C.c_size_t, [P(AttnDesc)]),
     "lav_attention_build_bias": (i32, [vp, P(AttnDesc)]),
     "lav_patch_im2col": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -704,6 +704,7 @@ extern "C" int lav_attention_fwd(void* stream, const lav_attn_desc* d, const voi
     LAV_REQUIRE(qkv && out, "lav_attention_fwd: null pointer");
     a.qkv = (const bf16_t*)qkv; a.o_w = (bf16_t*)out; a.lse = lse;
     if (d->mode == 0 && d->comb) return win_persistent_fwd(stream, a);
+    if (winl_supported(a)) return winl_fwd_launch(stream, a, problems);
     if (seq3_supported(a)) return seq3_fwd(stream, a, problems);
     hipStream_t s = (hipStream_t)stream;
     const int KL = d->mode == 0 ? WIN_KL : SEQ_KL_FWD;
@@ -738,6 +739,7 @@ extern "C" int lav_attention_bwd(void* stream, const lav_attn_desc* d, const voi
     a.dqkv = (bf16_t*)dqkv; a.dbias = dbias_table;
     float* delta = (float*)lse + (size_t)problems * d->heads * a.Npad;
     if (d->mode == 0 && d->comb) return win_persistent_bwd(stream, a, delta);
+    if (winl_supported(a)) return winl_bwd_launch(stream, a, problems, delta);
     if (seq3_supported(a)) return seq3_bwd(stream, a, problems, delta);
     hipStream_t s = (hipStream_t)stream;
     const int qgroups = (a.nqt + 3) / 4;
@@ -779,7 +781,7 @@ extern "C" int lav_attention_bwd(void* stream, const lav_attn_desc* d, const voi
     return lav_check_launch("lav_attention_bwd");
 }
 
-// Bias-table gradient alone (window mode, N <= 256 fast path): needs the forward's lse and the -delta scratch that
+// Bias-table gradient alone (window mode; persistent N <= 256 path or large-window path): needs the forward's lse and the -delta scratch that
 // lav_attention_bwd (called first, with dbias_table = NULL) left behind the lse in the same buffer.  A parameter gradient:
 // the engine issues it on the weight-gradient stream.
 extern "C" int lav_attention_bwd_bias(void* stream, const lav_attn_desc* d, const void* qkv, const void* dout, const float* lse,
@@ -787,8 +789,17 @@ extern "C" int lav_attention_bwd_bias(void* stream, const lav_attn_desc* d, cons
     AttnArgs a; int problems = 0;
     if (int rc = attn_setup(d, a, problems)) return rc;
     LAV_REQUIRE(qkv && dout && lse && dbias_table, "lav_attention_bwd_bias: null pointer");
-    LAV_REQUIRE(d->mode == 0 && d->comb, "lav_attention_bwd_bias: window mode with the precomputed tables (N <= 256) only");
     a.qkv = (const bf16_t*)qkv; a.dout = (const bf16_t*)dout; a.lse = (float*)lse; a.dbias = dbias_table;
+    if (d->mode == 0 && !d->comb && winl_supported(a)) return winl_dbias_launch(stream, a, problems, lse + (size_t)problems * d->heads * a.Npad);
+    LAV_REQUIRE(d->mode == 0 && d->comb, "lav_attention_bwd_bias: window mode on the persistent (N <= 256, tables given) or large-window (N <= 768) path only");
     return win_persistent_dbias(stream, a, lse + (size_t)problems * d->heads * a.Npad);
+}
+
+// 1 when the bias-table gradient of this descriptor can run as its own launch (lav_attention_bwd with dbias_table = NULL, then
+// lav_attention_bwd_bias on any stream that waits for it), 0 when lav_attention_bwd has to produce it.
+extern "C" int lav_attention_bias_split(const lav_attn_desc* d) {
+    AttnArgs a; int problems = 0;
+    if (attn_setup(d, a, problems)) return 0;
+    return d->mode == 0 && (d->comb || winl_supported(a)) ? 1 : 0;
 }
 

@@ -29,6 +29,11 @@ int attn_setup(const lav_attn_desc* d, AttnArgs& a, int& problems);
 int win_persistent_fwd(void* stream, const AttnArgs& a);
 int win_persistent_bwd(void* stream, const AttnArgs& a, float* ndelta);     // dQ, dK, dV (+ bias gradient when a.dbias)
 int win_persistent_dbias(void* stream, const AttnArgs& a, const float* ndelta);
+// window mode without the precomputed tables, N <= 768 (attention_winl.hip)
+bool winl_supported(const AttnArgs& a);
+int winl_fwd_launch(void* stream, const AttnArgs& a, int nwin);
+int winl_bwd_launch(void* stream, const AttnArgs& a, int nwin, float* delta);     // dQ, dK, dV (+ bias gradient when a.dbias)
+int winl_dbias_launch(void* stream, const AttnArgs& a, int nwin, const float* delta);
 // sequence mode, L <= 288 (attention_seq.hip)
 bool seq3_supported(const AttnArgs& a);
 int seq3_fwd(void* stream, const AttnArgs& a, int problems);

@@ -252,7 +252,7 @@ class Attn:
     @property
     def split_bias_grad(self):
         """True when the bias-table gradient can run as its own launch (bwd(..., dbias=None) then bwd_bias on any stream)."""
-        return self.d.mode == 0 and bool(self.d.comb)
+        return bool(L.lib.lav_attention_bias_split(C.byref(self.d)))
 
     def bwd_bias(self, qkv, dout, lse, dbias):
         L.check(L.lib.lav_attention_bwd_bias(_s(), C.byref(self.d), _p(qkv), _p(dout), _p(lse), _p(dbias)), "lav_attention_bwd_bias")

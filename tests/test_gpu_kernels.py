@@ -335,17 +335,35 @@ def _win_ref(qkv, table, B, D, H, W, C, heads, win, shift, cfg):
     (3, 5, 14, 14, 64, 2, (5, 7, 7), (0, 0, 0)),        # unshifted
     (2, 4, 14, 7, 32, 1, (4, 7, 7), (0, 3, 0)),         # N=196, one axis clamped
     (2, 1, 14, 14, 32, 1, (1, 7, 7), (0, 3, 3)),        # N=49 (image-text data, T=1)
-    (1, 16, 14, 14, 32, 1, (8, 7, 7), (4, 3, 3)),       # N=392 > 256: generic kernels, temporal shift
+    (1, 16, 14, 14, 32, 1, (8, 7, 7), (4, 3, 3)),       # N=392 > 256: large-window kernels, temporal shift
+    (1, 5, 24, 24, 64, 2, (5, 12, 12), (0, 6, 6), (8, 12, 12)),   # N=720 (Swin-L 384^2), shifted: windows with 1, 2 and 4 regions; 3 query parts
+    (2, 5, 12, 24, 32, 1, (5, 12, 12), (0, 0, 0), (8, 12, 12)),   # N=720 unshifted
+    (90, 5, 12, 12, 32, 1, (5, 12, 12), (0, 0, 0), (8, 12, 12)),  # N=720, 270 items on 256 workgroups (persistent walk)
+    (2, 5, 24, 24, 64, 2, (5, 12, 12), (0, 6, 6), (8, 12, 12), 1),  # N=720 shifted, whole problems per workgroup (the many-problem form)
 ])
 def test_window_attention_fwd_bwd(case):
-    B, D, H, W, C, heads, win, shift = case
-    cfg = (8, 7, 7)
+    B, D, H, W, C, heads, win, shift = case[:8]
+    cfg = case[8] if len(case) > 8 and case[8] else (8, 7, 7)
     M = B * D * H * W
     qkv = rb(M, 3 * C)
-    table = (0.5 * torch.randn(15 * 13 * 13, heads)).cuda()
+    table = (0.5 * torch.randn((2 * cfg[0] - 1) * (2 * cfg[1] - 1) * (2 * cfg[2] - 1), heads)).cuda()
     att = K().Attn(0, heads, 32, B=B, D=D, H=H, W=W, wd=win[0], wh=win[1], ww=win[2], sd=shift[0], sh=shift[1], sw=shift[2],
                    cfg_wd=cfg[0], cfg_wh=cfg[1], cfg_ww=cfg[2], bias_table=table)
     assert (win[0] * win[1] * win[2] <= 256) == hasattr(att, "comb")
+    if len(case) > 9:
+        from lavender_amd import _lib
+        old_parts = _lib.lib.lav_winl_select(case[9])
+        try:
+            _window_attention_check(att, case, qkv, table, cfg)
+        finally:
+            _lib.lib.lav_winl_select(old_parts)
+    else:
+        _window_attention_check(att, case, qkv, table, cfg)
+
+
+def _window_attention_check(att, case, qkv, table, cfg):
+    B, D, H, W, C, heads, win, shift = case[:8]
+    M = B * D * H * W
     lse = torch.empty(att.lse_elems(), device="cuda")
     out = torch.empty(M, C, dtype=bf16, device="cuda")
     att.fwd(qkv, out, lse)
