@@ -70,6 +70,11 @@ typedef struct lav_gemm_epilogue {
     int gelu_in_is_grad;      /* backward: gelu_in already holds GELU'(z) (1: bf16, 2: the one-byte code above, ldg in bytes) */
     int residual_f32;         /* residual is fp32 [M, ldr] (the fp32 residual stream of the post-LN fusion encoder:
                                  pre = x + dropout(dense(.)) is then stored fp32 with out_mode 1) */
+    const int* a_rowmap;      /* layout 0, N % 256 == 0, K % 64 == 0, splits == 1: logical row m of A is physical row a_rowmap[m]
+                                 (int32 [M], device).  The B x B pair expansion of the retrieval / VTM callers
+                                 (main_retrieval_mlm.py:62-87, main_pretrain_mlm.py:74-111): the (pairs, L, H) fusion input is never
+                                 materialised, the first layer's QKV GEMM reads the video / text rows of each pair through this map */
+    const int* res_rowmap;    /* residual row of output row m is res_rowmap[m] (same use: the first layer's residual is the un-expanded input) */
 } lav_gemm_epilogue;
 
 int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B, long ldb,

@@ -229,11 +229,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
                     }
                 }
                 if (has_res) {
+                    const long rrow = e.res_rowmap ? e.res_rowmap[grow] : grow;
                     if (e.residual_f32) {
-                        const float* rp = (const float*)e.residual + (long)grow * e.ldr + gcol;
+                        const float* rp = (const float*)e.residual + rrow * e.ldr + gcol;
                         pre_r[u] = *(const uint4*)rp; pre_r2[u] = *(const uint4*)(rp + 4);
                     } else {
-                        pre_r[u] = *(const uint4*)((const bf16_t*)e.residual + (long)grow * e.ldr + gcol);
+                        pre_r[u] = *(const uint4*)((const bf16_t*)e.residual + rrow * e.ldr + gcol);
                     }
                 }
             }
@@ -316,11 +317,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             for (int x = 0; x < 8; ++x) v[x] *= s;
         }
         if (has_res) {
-            const bf16_t* p = (const bf16_t*)e.residual + (long)grow * e.ldr + gcol;
+            const long rrow = (!full && e.res_rowmap) ? e.res_rowmap[grow] : grow;     // the full-chunk path used the preloaded rows
+            const bf16_t* p = (const bf16_t*)e.residual + rrow * e.ldr + gcol;
             float h[8];
             if (e.residual_f32) {
                 if (full) { *(uint4*)&h[0] = pre_r[u]; *(uint4*)&h[4] = pre_r2[u]; }
-                else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? ((const float*)e.residual)[(long)grow * e.ldr + gcol + x] : 0.f;
+                else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? ((const float*)e.residual)[rrow * e.ldr + gcol + x] : 0.f;
             } else if (full) unpack8(pre_r[u], h);
             else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? bf2f(p[x]) : 0.f;
 #pragma unroll
@@ -823,10 +825,26 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
         union { uint4 u; bf16x8 b; } o; o.u = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); ones = o.b;
     }
 
+    // K-contiguous A through an optional row map (pair expansion, lav_gemm_epilogue.a_rowmap): a lane's IPA source rows are fixed
+    // over the k-loop, so the map is read once here and the k-loop's DMA stream stays free of register-destination loads
+    const bf16_t* arow[AKC ? IPA : 1];
+    if constexpr (AKC) {
+#pragma unroll
+        for (int i = 0; i < IPA; ++i) {
+            int r = min(m0 + (wave * IPA + i) * 8 + (lane >> 3), g.M - 1);
+            if (g.e.a_rowmap) r = g.e.a_rowmap[r];
+            arow[i] = g.A + (long)r * g.lda + ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
+        }
+    }
     auto issue = [&](int kt) {
         char* st = smem + (kt & 1) * STAGE;
         const int k0 = kbeg + kt * BKT;
-        if (AKC) big_glds<true, IPA>(st, g.A, g.lda, m0, g.M, k0, wave, lane);
+        if constexpr (AKC) {
+#pragma unroll
+            for (int i = 0; i < IPA; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(arow[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(st + (wave * IPA + i) * 1024), 16, 0, 0);
+        }
         else huge_glds_strided<IPW>(st, g.A, g.lda, m0, g.M, k0, wave, lane);
         if (BKC) big_glds<true, IPB>(st + BOFF, g.B, g.ldb, n0, g.N, k0, wave, lane);
         else huge_glds_strided<IPW>(st + BOFF, g.B, g.ldb, n0, g.N, k0, wave, lane);
@@ -1534,6 +1552,16 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     // 192-row tiles where they fill the machine better (narrow outputs: N = 768 at M = 45120 is 2.07 rounds of 256-row tiles)
     const long t_h192 = (long)((M + 191) / 192) * (N / 256);
     const double f_h192 = ((N % 256) == 0 && fsel != EF_ALL && lav_gemm_h192) ? fill(t_h192, 256, 0.97) : 0.0;
+    if (g.e.a_rowmap) {                                      // pair-expanded A rows: the 256 x 256 kernel reads them through the map
+        LAV_REQUIRE(layout == 0 && splits == 1 && (N % 256) == 0 && (K % BKT) == 0,
+                    "lav_gemm_bf16: a_rowmap needs layout 0, splits 1, N %% 256 == 0 and K %% 64 == 0 (got layout %d, N %d, K %d)", layout, N, K);
+        g.k_per_split = K;
+        const int tn_ = N / 256;
+        g.group_n = lav_gemm_group_n >= 0 ? lav_gemm_group_n : (tn_ >= 8 && tn_ % 4 == 0 ? 4 : 0);
+        dim3 hgrid((unsigned)t_huge);
+        LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
+        return lav_check_launch("lav_gemm_bf16");
+    }
     if (big && lav_gemm_q && layout == 0 && fsel != EF_ALL && (N % 128) == 0 && (lav_gemm_q != 9 || (N <= 768 && K >= 2048 && M >= 16384))) {
         g.k_per_split = K;
         g.dbg = lav_gemm_dbg;

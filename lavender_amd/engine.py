@@ -380,6 +380,34 @@ class TextEmbedFn(torch.autograd.Function):
         return None, None, None, None
 
 
+def pair_index(B, Lv, nt, X, vi, ti):
+    """(n, L) int32 map: row r of pair k's sequence [video rows of clip vi[k] | text rows of text ti[k]] -> row of the un-expanded
+    source [B * Lv video rows ; nt * X text rows] (T.cat at model.py:235 over the pair list of main_pretrain_mlm.py:74-111 /
+    main_retrieval_mlm.py:62-87)."""
+    vi = np.asarray(vi, dtype=np.int64)
+    ti = np.asarray(ti, dtype=np.int64)
+    idx = np.empty((len(vi), Lv + X), dtype=np.int32)
+    idx[:, :Lv] = vi[:, None] * Lv + np.arange(Lv)[None, :]
+    idx[:, Lv:] = B * Lv + ti[:, None] * X + np.arange(X)[None, :]
+    return idx
+
+
+def pair_csr(flat, n_src):
+    """inverse of a pair map as (start, order): source row u is read by the pair rows order[start[u]:start[u + 1]]"""
+    order = np.argsort(flat, kind="stable").astype(np.int32)
+    start = np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=n_src))]).astype(np.int32)
+    return start, order
+
+
+# the first fusion layer reads its input THROUGH the pair map (lav_gemm_epilogue.a_rowmap / res_rowmap) instead of a gathered
+# (pairs, L, H) copy; needs the 256-column GEMM tiles.  LAV_PAIR_FUSED=0 restores the materialised gather (PairSeqFn).
+PAIR_FUSED = os.environ.get("LAV_PAIR_FUSED", "1") != "0"
+
+
+def pair_fused_ok(Hd):
+    return PAIR_FUSED and Hd % 64 == 0 and (3 * Hd) % 256 == 0
+
+
 class PairSeqFn(torch.autograd.Function):
     """Builds the fusion input [video rows of sample vi | text rows of sample ti] for every pair
     (T.cat at model.py:235 + the pair list of main_pretrain_mlm.py:74-111) with one row-gather kernel;
@@ -393,16 +421,10 @@ class PairSeqFn(torch.autograd.Function):
         L = Lv + X
         dev = f_img.device
         src = torch.cat([f_img.reshape(B * Lv, Hd), f_txt.reshape(nt * X, Hd)], 0)
-        vi = np.asarray(vi, dtype=np.int64)
-        ti = np.asarray(ti, dtype=np.int64)
-        idx = np.empty((n, L), dtype=np.int32)
-        idx[:, :Lv] = vi[:, None] * Lv + np.arange(Lv)[None, :]
-        idx[:, Lv:] = B * Lv + ti[:, None] * X + np.arange(X)[None, :]
-        flat = idx.reshape(-1)
+        flat = pair_index(B, Lv, nt, X, vi, ti).reshape(-1)
         out = K.gather_rows(src, torch.from_numpy(flat).to(dev, non_blocking=True), n * L, Hd)
         if _keep(ctx):
-            order = np.argsort(flat, kind="stable").astype(np.int32)
-            start = np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=B * Lv + nt * X))]).astype(np.int32)
+            start, order = pair_csr(flat, B * Lv + nt * X)
             ctx.csr = (torch.from_numpy(start).to(dev, non_blocking=True), torch.from_numpy(order).to(dev, non_blocking=True))
             ctx.meta = (B, Lv, X, Hd, n, nt)
         return out.view(n, L, Hd)
@@ -444,10 +466,17 @@ class BertLayerFn(torch.autograd.Function):
     """One post-LN BertLayer of the fusion encoder (HF BertLayer as called from model.py:242)."""
 
     @staticmethod
-    def forward(ctx, anchor, x, x32, layer, key_mask, n, L, p_hidden, p_attn, want32, causal_from=0):
+    def forward(ctx, anchor, x, x32, layer, key_mask, n, L, p_hidden, p_attn, want32, causal_from=0, pair=None):
         """x: (R, H) bf16 layer input (GEMM operand); x32: its fp32 copy for the residual add, or None (first layer:
-        the embeddings are bf16); returns (y bf16, y32 fp32 or None when want32 is false)."""
-        R, Hd = x.shape
+        the embeddings are bf16); returns (y bf16, y32 fp32 or None when want32 is false).
+        pair = (rowmap, start, order) (first layer only): x holds the UN-EXPANDED rows [video rows of every clip ; text rows of
+        every text] and row r of the n * L pair rows is x[rowmap[r]] -- the QKV GEMM and the residual add read x through the map,
+        the (n, L, H) expansion of main_retrieval_mlm.py:62-87 / main_pretrain_mlm.py:74-111 never exists; (start, order) is the
+        map's inverse for the backward."""
+        Hd = x.shape[1]
+        R = n * L
+        rowmap = pair[0] if pair is not None else None
+        assert pair is not None or x.shape[0] == R
         f32 = torch.float32
         sdt = f32 if STREAM32 else bf16
         heads = layer.num_heads
@@ -456,7 +485,7 @@ class BertLayerFn(torch.autograd.Function):
         wqkv16, _, _ = arena.fused_view(att_m.query.weight, 3 * Hd)
         _, _, bqkv = arena.fused_view(att_m.query.bias, 3 * Hd)
         keep = _keep(ctx)
-        qkv = K.gemm(0, x, wqkv16, R, 3 * Hd, Hd, bias=bqkv)
+        qkv = K.gemm(0, x, wqkv16, R, 3 * Hd, Hd, bias=bqkv, a_rowmap=rowmap)
         s_att, s1, s2 = K.next_seed(), K.next_seed(), K.next_seed()
         att = K.Attn(1, heads, Hd // heads, n_seq=n, L=L, key_mask=key_mask, dropout_p=p_attn, seed=s_att, causal_from=int(causal_from))
         lse = torch.empty(att.lse_elems(), dtype=torch.float32, device=x.device) if keep else None
@@ -464,7 +493,7 @@ class BertLayerFn(torch.autograd.Function):
         att.fwd(qkv, cx, lse)
         ao = layer.attention.output
         pre1 = K.gemm(0, cx, W16(ao.dense.weight), R, Hd, Hd, bias=ao.dense.bias.data, dropout_p=p_hidden, seed=s1,
-                      residual=x32 if x32 is not None else x, out_dtype=sdt)
+                      residual=x32 if x32 is not None else x, res_rowmap=rowmap, out_dtype=sdt)
         x1_32 = torch.empty((R, Hd), dtype=f32, device=x.device) if STREAM32 else None
         x1, mean1, rstd1 = K.layernorm_fwd(pre1, R, Hd, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, ao.LayerNorm.eps,
                                            want_stats=keep, out32=x1_32)
@@ -479,6 +508,7 @@ class BertLayerFn(torch.autograd.Function):
                                           want_stats=keep, out32=y32)
         if keep:
             ctx.layer, ctx.att, ctx.seeds, ctx.p = layer, att, (s1, s2), p_hidden
+            ctx.pair = pair
             ctx.save_for_backward(x, qkv, cx, lse, pre1, mean1, rstd1, x1, h_pre, h, pre2, mean2, rstd2)
         ctx.mark_non_differentiable(*([y32] if y32 is not None else []))
         return y, y32
@@ -487,7 +517,7 @@ class BertLayerFn(torch.autograd.Function):
     def backward(ctx, dy, _dy32=None):
         layer, att, (s1, s2), p = ctx.layer, ctx.att, ctx.seeds, ctx.p
         x, qkv, cx, lse, pre1, mean1, rstd1, x1, h_pre, h, pre2, mean2, rstd2 = ctx.saved_tensors
-        R, Hd = x.shape
+        R, Hd = cx.shape
         arena = layer._arena()
         att_m, ao, inter, outp = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
         F = inter.dense.weight.shape[0]
@@ -511,9 +541,19 @@ class BertLayerFn(torch.autograd.Function):
         d_cx = K.gemm(0, d_dense1, W16T(ao.dense.weight), R, Hd, Hd)
         dqkv = torch.empty_like(qkv)
         att.bwd(qkv, cx, d_cx, lse, dqkv, None)
+        if ctx.pair is not None:
+            # every pair row that read source row u sends its gradient back to u: sum the pair rows first (one gather-sum each
+            # for dqkv and the residual branch), then the weight gradient and the input gradient run on the U source rows
+            _, start, order = ctx.pair
+            U = x.shape[0]
+            dqkv_u = K.gather_sum_rows(dqkv, start, order, U, 3 * Hd)
+            d_pre1_u = K.gather_sum_rows(d_pre1, start, order, U, Hd)
+            dw_gemm(dqkv_u, x, 3 * Hd, Hd, U, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, U), rowsum_a=gbqkv)
+            dx = K.gemm(0, dqkv_u, W16T(att_m.query.weight), U, Hd, 3 * Hd, residual=d_pre1_u)
+            return None, dx, None, None, None, None, None, None, None, None, None, None
         dw_gemm(dqkv, x, 3 * Hd, Hd, R, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, R), rowsum_a=gbqkv)
         dx = K.gemm(0, dqkv, W16T(att_m.query.weight), R, Hd, 3 * Hd, residual=d_pre1)
-        return None, dx, None, None, None, None, None, None, None, None, None
+        return None, dx, None, None, None, None, None, None, None, None, None, None
 
 
 class MLMHeadFn(torch.autograd.Function):

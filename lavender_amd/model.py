@@ -193,45 +193,64 @@ class LAVENDER_Base(nn.Module):
             return mask
         return torch.cat([mask_img, mask_txt], dim=1)
 
-    def _encode(self, feat, mask, causal_from=0):
+    def _encode(self, feat, mask, causal_from=0, pair=None):
         """feat (n, L, H) bf16, mask (n, L) 0/1 key mask -> last_hidden_state (n, L, H).  causal_from > 0: seq2seq mask with that
-        many prefix (video) keys (lav_attn_desc.causal_from)."""
+        many prefix (video) keys (lav_attn_desc.causal_from).  pair = (rowmap, start, order): feat is the UN-EXPANDED (U, H) source
+        and the first layer reads it through the pair map (engine.BertLayerFn)."""
         arena = self.arena()
         arena.sync_half_if_stale()                            # e.g. load_ckpt followed directly by a 'cross' call on cached features
-        n, L, Hd = feat.shape
+        n, L = mask.shape
+        Hd = feat.shape[-1]
         km = mask.to(torch.int32).contiguous()
-        x = feat.reshape(n * L, Hd)
+        x = feat.reshape(-1, Hd)
         if not x.is_contiguous():
             x = x.contiguous()
         ph = self.config.hidden_dropout_prob if self.training else 0.0
         pa = self.config.attention_probs_dropout_prob if self.training else 0.0
         x32, last = None, len(self.trsfr.layer) - 1
         for i, lyr in enumerate(self.trsfr.layer):
-            x, x32 = E.BertLayerFn.apply(arena.anchor, x, x32, lyr, km, n, L, ph, pa, i < last, int(causal_from))
+            x, x32 = E.BertLayerFn.apply(arena.anchor, x, x32, lyr, km, n, L, ph, pa, i < last, int(causal_from), pair if i == 0 else None)
         return x.view(n, L, Hd)
+
+    def _pair_source(self, feat_img, feat_txt, vi, ti):
+        """([video rows of every clip ; text rows of every text] (U, H), (rowmap, start, order)) for the fused pair expansion, or
+        (the gathered (n, L, H) input, None) where the map-reading GEMM tiles do not apply."""
+        B, Lv, Hd = feat_img.shape
+        nt, X = feat_txt.shape[0], feat_txt.shape[1]
+        if not E.pair_fused_ok(Hd):
+            return E.PairSeqFn.apply(feat_img, feat_txt, vi, ti), None
+        dev = feat_img.device
+        flat = E.pair_index(B, Lv, nt, X, vi, ti).reshape(-1)
+        src = torch.cat([feat_img.reshape(B * Lv, Hd), feat_txt.reshape(nt * X, Hd)], 0)       # U rows: one copy of each clip / text
+        pair = [torch.from_numpy(flat).to(dev, non_blocking=True), None, None]
+        if torch.is_grad_enabled():
+            start, order = E.pair_csr(flat, B * Lv + nt * X)
+            pair[1] = torch.from_numpy(start).to(dev, non_blocking=True)
+            pair[2] = torch.from_numpy(order).to(dev, non_blocking=True)
+        return src, tuple(pair)
 
     def go_cross(self, feat_img, mask_img, feat_txt, mask_txt, attn_mask_type="full", feat_pretxt=None, mask_pretxt=None):
         if feat_pretxt is not None:
             raise NotImplementedError("prompt / task-token pre-text (model.py:228-232) is outside the pretrain hot path")
         n = feat_img.shape[0]
         ident = np.arange(n)
-        feat = E.PairSeqFn.apply(feat_img, feat_txt, ident, ident)
+        feat, pair = self._pair_source(feat_img, feat_txt, ident, ident)
         if attn_mask_type == "seq2seq":
             # (B, L, L) mask of get_attn_mask in kernel form: video keys by mask_img, text keys all valid but causal
             key_mask = torch.cat([mask_img, torch.ones_like(mask_txt)], dim=1)
-            return self._encode(feat, key_mask, causal_from=mask_img.shape[1]), _NO_ATTN
+            return self._encode(feat, key_mask, causal_from=mask_img.shape[1], pair=pair), _NO_ATTN
         mask = self.get_attn_mask(mask_img, mask_txt, attn_mask_type=attn_mask_type)
-        assert feat.shape[1] == mask.shape[1], f"mask and feat must have the same length, got {feat.shape[1]} vs. {mask.shape[1]}"
-        return self._encode(feat, mask), _NO_ATTN
+        assert feat_img.shape[1] + feat_txt.shape[1] == mask.shape[1], f"mask and feat must have the same length, got {feat_img.shape[1] + feat_txt.shape[1]} vs. {mask.shape[1]}"
+        return self._encode(feat, mask, pair=pair), _NO_ATTN
 
     def go_cross_pairs(self, feat_img, mask_img, feat_txt, mask_txt, vi, ti):
         """go_cross on the pair list (video vi[k], text ti[k]) without materialising per-pair copies in Python
         (replaces the list building + T.cat of main_pretrain_mlm.py:74-111)."""
-        feat = E.PairSeqFn.apply(feat_img, feat_txt, vi, ti)
+        feat, pair = self._pair_source(feat_img, feat_txt, vi, ti)
         vi_t = torch.as_tensor(np.asarray(vi), device=mask_img.device)
         ti_t = torch.as_tensor(np.asarray(ti), device=mask_img.device)
         mask = torch.cat([mask_img[vi_t], mask_txt[ti_t]], dim=1)
-        return self._encode(feat, mask), _NO_ATTN
+        return self._encode(feat, mask, pair=pair), _NO_ATTN
 
     def prepro_txt_inputs(self, txt, mask_txt, feat_txt, task_name=None, prompt=None):
         """model.py:292-307 with enable_task_token / enable_prompt off (the shipped pretrain config): identity."""

@@ -306,6 +306,28 @@ def test_layernorm_patch_merge_gather():
     close(dx.view(BT, H, W, C0), xr.grad, atol=3e-2, what="gather LN scatter-back")
 
 
+def test_gemm_reads_a_and_residual_through_a_row_map():
+    """lav_gemm_epilogue.a_rowmap / res_rowmap (the fused B x B pair expansion): same bits as the GEMM on the gathered operand."""
+    U, M, N, Kd = 700, 2 * 276 + 5, 768, 768
+    src = rb(U, Kd, seed=1)
+    W = rb(N, Kd, seed=2) * 0.05
+    bias = torch.randn(N, device="cuda")
+    g = torch.Generator().manual_seed(3)
+    rowmap = torch.randint(0, U, (M,), generator=g, dtype=torch.int32).cuda()
+    gathered = src[rowmap.long()].contiguous()
+    y0 = K().gemm(0, gathered, W, M, N, Kd, bias=bias)
+    y1 = K().gemm(0, src, W, M, N, Kd, bias=bias, a_rowmap=rowmap)
+    torch.cuda.synchronize()
+    ref = gathered.float() @ W.float().t() + bias
+    close(y1, ref, atol=3e-2, rtol=2e-2, what="row-mapped GEMM vs fp32 reference")
+    # fp32-out + dropout + residual form of the first fusion layer's output projection, residual rows through the map
+    y2 = K().gemm(0, gathered, W, M, N, Kd, bias=bias, dropout_p=0.1, seed=11, residual=gathered, out_dtype=torch.float32)
+    y3 = K().gemm(0, src, W, M, N, Kd, bias=bias, dropout_p=0.1, seed=11, residual=src, res_rowmap=rowmap, a_rowmap=rowmap, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y3)
+    close(y0, ref, atol=3e-2, rtol=2e-2, what="gathered GEMM vs fp32 reference")
+
+
 # ---------------------------------------------------------------------------------------------- attention
 def _win_ref(qkv, table, B, D, H, W, C, heads, win, shift, cfg):
     """window attention of video_swin.py:145-170,218-239 on a (tokens, 3C) qkv tensor via the oracle helpers."""
