@@ -57,3 +57,17 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 L.lib = real
 print(f"host-only (C-ABI calls stubbed out) {1e3*(t1-t0)/n:.1f} ms/step")
+
+# where the host time goes: cProfile over a few steps (cumulative time, top entries)
+if os.environ.get("LAV_HOST_PROFILE"):
+    import cProfile, pstats, io
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    pr.enable()
+    for _ in range(5):
+        ag.step(batch, True, sync=False)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = io.StringIO()
+    pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(28)
+    print(st.getvalue()[:6000])
