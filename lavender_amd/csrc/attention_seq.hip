@@ -11,8 +11,10 @@
 //   * 256-thread workgroups, two per CU (74-76 KB of LDS each): while one waits for its next problem's image the other computes.
 //     A workgroup walks problems blockIdx.x, blockIdx.x + gridDim.x, ...; its four waves take the 32-row tiles round-robin.
 //   * the S tile of step t+1 is issued before the softmax of step t (matrix pipe under the VALU chain of the same wave).
-// Longer sequences (the 757-token Swin-L-384 shape) stay on the generic kernels of attention.hip.
+// Longer sequences (the 757-token Swin-L-384 shape, up to 768) run the chunked kernels at the end of this file; beyond that the generic
+// kernels of attention.hip.
 #include "attn_common.h"
+#include <stdlib.h>
 
 #define LOG2E 1.4426950408889634f
 #define HD 64
@@ -442,6 +444,425 @@ __global__ __launch_bounds__(256, 2) void seq_dkv3(AttnArgs a, int nprob, const 
     }
 }
 
+// ======================================================================================================
+// Long sequences (288 < L <= 768: the 757-token Swin-L-384 fusion input): same tile code, but a (sequence, head) problem no
+// longer fits LDS whole.  512-thread workgroups; a work item is (problem, part): wave w owns ONE 32-row tile, part * 8 + w
+// (queries in the forward / dQ pass, keys in the dK / dV pass), so the per-tile state (output accumulators, running max) lives
+// in registers across the whole walk, and the other operand streams through LDS in 256-row chunks, double-buffered: chunk
+// c + 1 is in flight (global_load_lds) under chunk c's MFMAs.  LDS: [2][image A 32 KB | image B 32 KB] + per-row floats.
+// ======================================================================================================
+#define SEQL_ROWS 768
+#define SEQL_CH 256                                         // rows per chunk
+#define SEQL_IMG (SEQL_CH * 128)
+#define SEQL_BUF (2 * SEQL_IMG)
+
+// DMA of rows [row0, row0 + 256) of an operand (clamped to the last row of the sequence): 32 one-KB pieces, 4 per wave
+__device__ __forceinline__ void seql_dma_chunk(unsigned lds_img, const bf16_t* base, long ld, int L, int row0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = wave * 4 + i;
+        const int prow = t * 8 + (lane >> 3);
+        const int row = min(row0 + prow, L - 1);
+        const int lslot = (lane & 7) ^ ((prow >> 1) & 7);
+        sdma16(lds_img + t * 1024, base, (unsigned)((row * ld + lslot * 8) * 2));
+    }
+}
+
+template <bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(512) void seql_fwd(AttnArgs a, int nprob, int parts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* kadd = (float*)(smem + 2 * SEQL_BUF);
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, C = a.C, ld = 3 * C;
+    const int nt = a.nqt, nch = (nt + 7) / 8;
+    const float sc = a.d.scale * LOG2E;
+    const float inv_keep = DROP ? 1.f / (1.f - a.d.dropout_p) : 1.f;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    bf16x8 ones0;
+    {
+        float e8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) e8[e] = j == 0 ? 1.f : 0.f;
+        ones0 = pack_frag(e8);
+    }
+    for (int it = blockIdx.x; it < nprob * parts; it += gridDim.x) {
+        const int p = it / parts, part = it - p * parts;
+        const int prob = p / a.d.heads, head = p - prob * a.d.heads;
+        const bf16_t* qbase = a.qkv + (long)prob * N * ld + head * HD;
+        const int qt = part * 8 + wave;
+        const bool active = qt < nt;                         // wave-uniform; idle waves still move their DMA pieces
+        const int q = qt * 32 + j;
+        const bool q_ok = active && q < N;
+        const long qrow = (long)min(q, N - 1);
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { SFrag f; f.u = *(const uint4*)(qbase + qrow * ld + ks * 16 + 8 * hi); qf[ks] = f.b; }
+        __syncthreads();                                     // every wave is done with the previous item's LDS
+        for (int k = tid; k < nt * 32; k += 512)
+            kadd[k] = (k >= N || (a.d.key_mask && a.d.key_mask[(long)prob * N + k] == 0)) ? -INFINITY : 0.f;
+        seql_dma_chunk(lds0, qbase + C, ld, N, 0, wave, lane);
+        seql_dma_chunk(lds0 + SEQL_IMG, qbase + 2 * C, ld, N, 0, wave, lane);
+        sdma_wait_all();
+        __syncthreads();
+        f32x16 o0 = SZERO16, o1 = SZERO16, lacc = SZERO16;
+        float m_run = -INFINITY;
+        const uint32_t drow = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)q) * (uint32_t)a.NH;
+        for (int c = 0; c < nch; ++c) {
+            const char* Ks = smem + (c & 1) * SEQL_BUF;
+            const char* Vs = Ks + SEQL_IMG;
+            if (c + 1 < nch) {
+                seql_dma_chunk(lds0 + ((c + 1) & 1) * SEQL_BUF, qbase + C, ld, N, (c + 1) * SEQL_CH, wave, lane);
+                seql_dma_chunk(lds0 + ((c + 1) & 1) * SEQL_BUF + SEQL_IMG, qbase + 2 * C, ld, N, (c + 1) * SEQL_CH, wave, lane);
+            }
+            const int ntc = min(8, nt - c * 8);
+            if (active) {
+                f32x16 sa, sb;
+                auto qk = [&](int tl, f32x16& s) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float4 m4 = *(const float4*)(kadd + (c * 8 + tl) * 32 + 8 * r4 + 4 * hi);
+                        s[4 * r4] = m4.x; s[4 * r4 + 1] = m4.y; s[4 * r4 + 2] = m4.z; s[4 * r4 + 3] = m4.w;
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        bf16x8 kf = *(const bf16x8*)(Ks + krow_off<HD>(tl * 32 + j, ks * 2 + hi));
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                    }
+                };
+                auto soft = [&](int tl, f32x16& s) {
+                    const int t = c * 8 + tl;
+                    if (CAUSAL) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int kk = t * 32 + tile_row(r, hi);
+                            if (kk >= a.d.causal_from && (q < a.d.causal_from || kk > q)) s[r] = -INFINITY;
+                        }
+                    }
+                    float mx = smax3(s[0], s[1], s[2]);
+#pragma unroll
+                    for (int r = 3; r < 15; r += 2) mx = smax3(mx, s[r], s[r + 1]);
+                    mx = fmaxf(mx, s[15]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+                    if (__any(mx > m_run)) {
+                        const float m_new = fmaxf(m_run, mx);
+                        const float alpha = fast_exp2(m_run - m_new);
+                        lacc[0] *= alpha;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                        m_run = m_new;
+                    }
+                    const float nm = m_run == -INFINITY ? 0.f : -m_run;
+                    uint32_t pk[8], pd[8];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const int r = r4 * 4 + 2 * e2;
+                            const float p0 = fast_exp2(fmaf(s[r], sc, nm)), p1 = fast_exp2(fmaf(s[r + 1], sc, nm));
+                            pk[r >> 1] = pack2(p0, p1);
+                            if (DROP) {
+                                float m0, m1;
+                                drop_pair(a.d.seed, drow + (uint32_t)((t * 32 + 4 * hi) >> 1) + (uint32_t)(4 * r4 + e2), a.thresh16, inv_keep, m0, m1);
+                                pd[r >> 1] = pack2(p0 * m0, p1 * m1);
+                            }
+                        }
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        SFrag pf, pq;
+                        pf.u = make_uint4(pk[4 * sl], pk[4 * sl + 1], pk[4 * sl + 2], pk[4 * sl + 3]);
+                        if (DROP) pq.u = make_uint4(pd[4 * sl], pd[4 * sl + 1], pd[4 * sl + 2], pd[4 * sl + 3]); else pq.u = pf.u;
+                        lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones0, pf.b, lacc, 0, 0, 0);
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Vs, tl * 32 + 16 * sl, 0, lane), pq.b, o0, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Vs, tl * 32 + 16 * sl, 32, lane), pq.b, o1, 0, 0, 0);
+                    }
+                };
+                qk(0, sa);
+#pragma unroll 1
+                for (int tl = 0; tl < ntc; tl += 2) {
+                    if (tl + 1 < ntc) qk(tl + 1, sb);
+                    soft(tl, sa);
+                    if (tl + 1 < ntc) {
+                        if (tl + 2 < ntc) qk(tl + 2, sa);
+                        soft(tl + 1, sb);
+                    }
+                }
+            }
+            sdma_wait_all();
+            __syncthreads();
+        }
+        const float l_tot = __shfl(lacc[0], j, 64);
+        const float inv_l = l_tot > 0.f ? 1.f / l_tot : 0.f;
+        if (q_ok) {
+            bf16_t* op = a.o_w + ((long)prob * N + q) * C + head * HD;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                uint2 w;
+                w.x = pack2(o0[r4 * 4 + 0] * inv_l, o0[r4 * 4 + 1] * inv_l);
+                w.y = pack2(o0[r4 * 4 + 2] * inv_l, o0[r4 * 4 + 3] * inv_l);
+                *(uint2*)(op + 8 * r4 + 4 * hi) = w;
+                w.x = pack2(o1[r4 * 4 + 0] * inv_l, o1[r4 * 4 + 1] * inv_l);
+                w.y = pack2(o1[r4 * 4 + 2] * inv_l, o1[r4 * 4 + 3] * inv_l);
+                *(uint2*)(op + 32 + 8 * r4 + 4 * hi) = w;
+            }
+            if (a.lse && hi == 0) a.lse[(long)p * a.Npad + q] = m_run + log2f(l_tot);
+        }
+    }
+}
+
+template <bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(512) void seql_dq(AttnArgs a, int nprob, int parts, float* delta_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* kadd = (float*)(smem + 2 * SEQL_BUF);
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, C = a.C, ld = 3 * C;
+    const int nt = a.nqt, nch = (nt + 7) / 8;
+    const float sc = a.d.scale * LOG2E;
+    const float inv_keep = DROP ? 1.f / (1.f - a.d.dropout_p) : 1.f;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    for (int it = blockIdx.x; it < nprob * parts; it += gridDim.x) {
+        const int p = it / parts, part = it - p * parts;
+        const int prob = p / a.d.heads, head = p - prob * a.d.heads;
+        const bf16_t* qbase = a.qkv + (long)prob * N * ld + head * HD;
+        const int qt = part * 8 + wave;
+        const bool active = qt < nt;
+        const int q = qt * 32 + j;
+        const bool q_ok = active && q < N;
+        const long qrow = (long)prob * N + min(q, N - 1);
+        bf16x8 qf[4], dof[4];
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            SFrag fq, fg, fo;
+            fq.u = *(const uint4*)(a.qkv + qrow * ld + head * HD + ks * 16 + 8 * hi);
+            fg.u = *(const uint4*)(a.dout + qrow * C + head * HD + ks * 16 + 8 * hi);
+            fo.u = *(const uint4*)(a.out + qrow * C + head * HD + ks * 16 + 8 * hi);
+            qf[ks] = fq.b; dof[ks] = fg.b;
+            float gf[8], of[8];
+            unpack8(fg.u, gf); unpack8(fo.u, of);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl = fmaf(gf[e], of[e], dl);
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        const float nl = q_ok ? -a.lse[(long)p * a.Npad + q] : -INFINITY;
+        if (q_ok && hi == 0) delta_out[(long)p * a.Npad + q] = dl;
+        const float ndl = -dl;
+        __syncthreads();
+        for (int k = tid; k < nt * 32; k += 512)
+            kadd[k] = (k >= N || (a.d.key_mask && a.d.key_mask[(long)prob * N + k] == 0)) ? -INFINITY : 0.f;
+        seql_dma_chunk(lds0, qbase + C, ld, N, 0, wave, lane);
+        seql_dma_chunk(lds0 + SEQL_IMG, qbase + 2 * C, ld, N, 0, wave, lane);
+        sdma_wait_all();
+        __syncthreads();
+        const uint32_t drow = ((uint32_t)(prob * a.d.heads + head) * (uint32_t)N + (uint32_t)q) * (uint32_t)a.NH;
+        f32x16 dq0 = SZERO16, dq1 = SZERO16;
+        for (int c = 0; c < nch; ++c) {
+            const char* Ks = smem + (c & 1) * SEQL_BUF;
+            const char* Vs = Ks + SEQL_IMG;
+            if (c + 1 < nch) {
+                seql_dma_chunk(lds0 + ((c + 1) & 1) * SEQL_BUF, qbase + C, ld, N, (c + 1) * SEQL_CH, wave, lane);
+                seql_dma_chunk(lds0 + ((c + 1) & 1) * SEQL_BUF + SEQL_IMG, qbase + 2 * C, ld, N, (c + 1) * SEQL_CH, wave, lane);
+            }
+            const int ntc = min(8, nt - c * 8);
+            if (active) {
+#pragma unroll 1
+                for (int tl = 0; tl < ntc; ++tl) {
+                    const int t = c * 8 + tl;
+                    f32x16 s, dp;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float4 m4 = *(const float4*)(kadd + t * 32 + 8 * r4 + 4 * hi);
+                        s[4 * r4] = m4.x; s[4 * r4 + 1] = m4.y; s[4 * r4 + 2] = m4.z; s[4 * r4 + 3] = m4.w;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dp[r] = DROP ? 0.f : ndl;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int off = krow_off<HD>(tl * 32 + j, ks * 2 + hi);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Ks + off), qf[ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Vs + off), dof[ks], dp, 0, 0, 0);
+                    }
+                    uint32_t dk[8];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const int r = r4 * 4 + 2 * e2;
+                            float p0 = fast_exp2(fmaf(s[r], sc, nl)), p1 = fast_exp2(fmaf(s[r + 1], sc, nl));
+                            if (CAUSAL) {
+                                const int kk = t * 32 + 8 * r4 + 4 * hi + 2 * e2;
+                                if (kk >= a.d.causal_from && (q < a.d.causal_from || kk > q)) p0 = 0.f;
+                                if (kk + 1 >= a.d.causal_from && (q < a.d.causal_from || kk + 1 > q)) p1 = 0.f;
+                            }
+                            if (DROP) {
+                                float m0, m1;
+                                drop_pair(a.d.seed, drow + (uint32_t)((t * 32 + 4 * hi) >> 1) + (uint32_t)(4 * r4 + e2), a.thresh16, inv_keep, m0, m1);
+                                dk[r >> 1] = pack2(p0 * fmaf(dp[r], m0, ndl), p1 * fmaf(dp[r + 1], m1, ndl));
+                            } else {
+                                dk[r >> 1] = pack2(p0 * dp[r], p1 * dp[r + 1]);
+                            }
+                        }
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        SFrag df; df.u = make_uint4(dk[4 * sl], dk[4 * sl + 1], dk[4 * sl + 2], dk[4 * sl + 3]);
+                        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Ks, tl * 32 + 16 * sl, 0, lane), df.b, dq0, 0, 0, 0);
+                        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Ks, tl * 32 + 16 * sl, 32, lane), df.b, dq1, 0, 0, 0);
+                    }
+                }
+            }
+            sdma_wait_all();
+            __syncthreads();
+        }
+        if (q_ok) {
+            bf16_t* op = a.dqkv + qrow * ld + head * HD;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                uint2 w;
+                w.x = pack2(dq0[r4 * 4 + 0] * a.d.scale, dq0[r4 * 4 + 1] * a.d.scale);
+                w.y = pack2(dq0[r4 * 4 + 2] * a.d.scale, dq0[r4 * 4 + 3] * a.d.scale);
+                *(uint2*)(op + 8 * r4 + 4 * hi) = w;
+                w.x = pack2(dq1[r4 * 4 + 0] * a.d.scale, dq1[r4 * 4 + 1] * a.d.scale);
+                w.y = pack2(dq1[r4 * 4 + 2] * a.d.scale, dq1[r4 * 4 + 3] * a.d.scale);
+                *(uint2*)(op + 32 + 8 * r4 + 4 * hi) = w;
+            }
+        }
+    }
+}
+
+// dK / dV: wave owns key tile part * 8 + w; Q and dO stream through LDS in 256-query chunks; lse (+inf for padded queries) and
+// delta of the whole sequence sit behind the buffers.
+template <bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(512) void seql_dkv(AttnArgs a, int nprob, int parts, const float* delta_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qlse = (float*)(smem + 2 * SEQL_BUF);
+    float* qdl = qlse + SEQL_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, C = a.C, ld = 3 * C;
+    const int nt = a.nqt, nch = (nt + 7) / 8;
+    const float sc = a.d.scale * LOG2E;
+    const float inv_keep = DROP ? 1.f / (1.f - a.d.dropout_p) : 1.f;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    for (int it = blockIdx.x; it < nprob * parts; it += gridDim.x) {
+        const int p = it / parts, part = it - p * parts;
+        const int prob = p / a.d.heads, head = p - prob * a.d.heads;
+        const bf16_t* qbase = a.qkv + (long)prob * N * ld + head * HD;
+        const bf16_t* gbase = a.dout + (long)prob * N * C + head * HD;
+        const int kt = part * 8 + wave;
+        const bool active = kt < nt;
+        const int key = kt * 32 + j;
+        const bool k_ok = active && key < N;
+        const long krow = (long)prob * N + min(key, N - 1);
+        const float k_add = (!k_ok || (a.d.key_mask && a.d.key_mask[(long)prob * N + min(key, N - 1)] == 0)) ? -INFINITY : 0.f;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            SFrag fk, fv;
+            fk.u = *(const uint4*)(a.qkv + krow * ld + C + head * HD + ks * 16 + 8 * hi);
+            fv.u = *(const uint4*)(a.qkv + krow * ld + 2 * C + head * HD + ks * 16 + 8 * hi);
+            kf[ks] = fk.b; vf[ks] = fv.b;
+        }
+        __syncthreads();
+        for (int k = tid; k < nt * 32; k += 512) {
+            qlse[k] = k < N ? a.lse[(long)p * a.Npad + k] : INFINITY;
+            qdl[k] = k < N ? delta_in[(long)p * a.Npad + k] : 0.f;
+        }
+        seql_dma_chunk(lds0, qbase, ld, N, 0, wave, lane);
+        seql_dma_chunk(lds0 + SEQL_IMG, gbase, C, N, 0, wave, lane);
+        sdma_wait_all();
+        __syncthreads();
+        f32x16 kadd16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kadd16[r] = k_add;
+        f32x16 dk0 = SZERO16, dk1 = SZERO16, dv0 = SZERO16, dv1 = SZERO16;
+        const uint32_t dcol = (uint32_t)(prob * a.d.heads + head) * (uint32_t)N;
+        const uint32_t sh = (uint32_t)(key & 1) * 16u;
+        for (int c = 0; c < nch; ++c) {
+            const char* Qs = smem + (c & 1) * SEQL_BUF;
+            const char* Gs = Qs + SEQL_IMG;
+            if (c + 1 < nch) {
+                seql_dma_chunk(lds0 + ((c + 1) & 1) * SEQL_BUF, qbase, ld, N, (c + 1) * SEQL_CH, wave, lane);
+                seql_dma_chunk(lds0 + ((c + 1) & 1) * SEQL_BUF + SEQL_IMG, gbase, C, N, (c + 1) * SEQL_CH, wave, lane);
+            }
+            const int ntc = min(8, nt - c * 8);
+            if (active) {
+#pragma unroll 1
+                for (int tl = 0; tl < ntc; ++tl) {
+                    const int q0 = (c * 8 + tl) * 32, l0 = tl * 32;
+                    f32x16 s = kadd16, dp = SZERO16;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int off = krow_off<HD>(l0 + j, ks * 2 + hi);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Qs + off), kf[ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Gs + off), vf[ks], dp, 0, 0, 0);
+                    }
+                    uint32_t pk[8], dsk[8];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int qb = q0 + 8 * r4 + 4 * hi;
+                        const float4 l4 = *(const float4*)(qlse + qb);
+                        const float4 d4 = *(const float4*)(qdl + qb);
+                        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+                        const float dls[4] = {d4.x, d4.y, d4.z, d4.w};
+                        float pv[4], dsv[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = r4 * 4 + e;
+                            float pe = fast_exp2(fmaf(s[r], sc, -ls[e]));
+                            if (CAUSAL) {
+                                const int qq = qb + e;
+                                if (key >= a.d.causal_from && (qq < a.d.causal_from || key > qq)) pe = 0.f;
+                            }
+                            float m = 1.f;
+                            if (DROP) {
+                                const uint32_t h = lav_hash32(a.d.seed, (dcol + (uint32_t)(qb + e)) * (uint32_t)a.NH + (uint32_t)(key >> 1));
+                                m = ((h >> sh) & 0xffffu) >= a.thresh16 ? inv_keep : 0.f;
+                            }
+                            pv[e] = DROP ? pe * m : pe;
+                            dsv[e] = pe * (DROP ? fmaf(dp[r], m, -dls[e]) : dp[r] - dls[e]);
+                        }
+                        pk[2 * r4] = pack2(pv[0], pv[1]); pk[2 * r4 + 1] = pack2(pv[2], pv[3]);
+                        dsk[2 * r4] = pack2(dsv[0], dsv[1]); dsk[2 * r4 + 1] = pack2(dsv[2], dsv[3]);
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        SFrag pf, df;
+                        pf.u = make_uint4(pk[4 * sl], pk[4 * sl + 1], pk[4 * sl + 2], pk[4 * sl + 3]);
+                        df.u = make_uint4(dsk[4 * sl], dsk[4 * sl + 1], dsk[4 * sl + 2], dsk[4 * sl + 3]);
+                        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Gs, l0 + 16 * sl, 0, lane), pf.b, dv0, 0, 0, 0);
+                        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Gs, l0 + 16 * sl, 32, lane), pf.b, dv1, 0, 0, 0);
+                        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Qs, l0 + 16 * sl, 0, lane), df.b, dk0, 0, 0, 0);
+                        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Qs, l0 + 16 * sl, 32, lane), df.b, dk1, 0, 0, 0);
+                    }
+                }
+            }
+            sdma_wait_all();
+            __syncthreads();
+        }
+        if (k_ok) {
+            bf16_t* op = a.dqkv + krow * ld + head * HD;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = 8 * r4 + 4 * hi;
+                uint2 w;
+                w.x = pack2(dk0[r4 * 4 + 0] * a.d.scale, dk0[r4 * 4 + 1] * a.d.scale);
+                w.y = pack2(dk0[r4 * 4 + 2] * a.d.scale, dk0[r4 * 4 + 3] * a.d.scale);
+                *(uint2*)(op + C + d) = w;
+                w.x = pack2(dk1[r4 * 4 + 0] * a.d.scale, dk1[r4 * 4 + 1] * a.d.scale);
+                w.y = pack2(dk1[r4 * 4 + 2] * a.d.scale, dk1[r4 * 4 + 3] * a.d.scale);
+                *(uint2*)(op + C + 32 + d) = w;
+                w.x = pack2(dv0[r4 * 4 + 0], dv0[r4 * 4 + 1]);
+                w.y = pack2(dv0[r4 * 4 + 2], dv0[r4 * 4 + 3]);
+                *(uint2*)(op + 2 * C + d) = w;
+                w.x = pack2(dv1[r4 * 4 + 0], dv1[r4 * 4 + 1]);
+                w.y = pack2(dv1[r4 * 4 + 2], dv1[r4 * 4 + 3]);
+                *(uint2*)(op + 2 * C + 32 + d) = w;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 template <typename Kn>
 static void seq_lds(Kn k, size_t bytes) {
@@ -449,7 +870,12 @@ static void seq_lds(Kn k, size_t bytes) {
     (void)hipGetLastError();
 }
 
-bool seq3_supported(const AttnArgs& a) { return a.d.mode == 1 && a.N <= SEQ3_ROWS; }
+static const bool lav_seql_on = getenv("LAV_SEQL") ? atoi(getenv("LAV_SEQL")) != 0 : true;   // probe hook: 0 = generic kernels for L > 288
+bool seq3_supported(const AttnArgs& a) {
+    if (a.d.mode != 1) return false;
+    if (a.N <= SEQ3_ROWS) return true;
+    return lav_seql_on && a.N <= SEQL_ROWS && (double)a.d.n_seq * a.N * 3.0 * a.C * 2.0 < 4.0e9;      // 32-bit DMA offsets per problem base are fine; keep the whole tensor below 4 GB anyway
+}
 
 #define SEQ3_DISPATCH(KERN, lds, ...)                                                                               \
     do {                                                                                                            \
@@ -463,9 +889,28 @@ bool seq3_supported(const AttnArgs& a) { return a.d.mode == 1 && a.N <= SEQ3_ROW
         }                                                                                                           \
     } while (0)
 
+#define SEQL_DISPATCH(KERN, lds, ...)                                                                               \
+    do {                                                                                                            \
+        const bool causal = a.d.causal_from > 0, drop = a.d.dropout_p > 0.f;                                        \
+        if (causal) {                                                                                               \
+            if (drop) { seq_lds(KERN<true, true>, lds); hipLaunchKernelGGL((KERN<true, true>), grid, dim3(512), lds, s, __VA_ARGS__); }   \
+            else { seq_lds(KERN<true, false>, lds); hipLaunchKernelGGL((KERN<true, false>), grid, dim3(512), lds, s, __VA_ARGS__); }      \
+        } else {                                                                                                    \
+            if (drop) { seq_lds(KERN<false, true>, lds); hipLaunchKernelGGL((KERN<false, true>), grid, dim3(512), lds, s, __VA_ARGS__); } \
+            else { seq_lds(KERN<false, false>, lds); hipLaunchKernelGGL((KERN<false, false>), grid, dim3(512), lds, s, __VA_ARGS__); }    \
+        }                                                                                                           \
+    } while (0)
+
 int seq3_fwd(void* stream, const AttnArgs& a, int problems) {
     hipStream_t s = (hipStream_t)stream;
     const int nprob = problems * a.d.heads;
+    if (a.N > SEQ3_ROWS) {
+        const int parts = (a.nqt + 7) / 8, items = nprob * parts;
+        const dim3 grid(items < 256 ? items : 256);
+        const size_t lds = 2 * SEQL_BUF + SEQL_ROWS * 4;
+        SEQL_DISPATCH(seql_fwd, lds, a, nprob, parts);
+        return lav_check_launch("lav_attention_fwd(long sequence)");
+    }
     const dim3 grid(nprob < 512 ? nprob : 512);
     const size_t lds = 2 * SEQ3_IMG + SEQ3_ROWS * 4;
     SEQ3_DISPATCH(seq_fwd3, lds, a, nprob);
@@ -475,6 +920,14 @@ int seq3_fwd(void* stream, const AttnArgs& a, int problems) {
 int seq3_bwd(void* stream, const AttnArgs& a, int problems, float* delta) {
     hipStream_t s = (hipStream_t)stream;
     const int nprob = problems * a.d.heads;
+    if (a.N > SEQ3_ROWS) {
+        const int parts = (a.nqt + 7) / 8, items = nprob * parts;
+        const dim3 grid(items < 256 ? items : 256);
+        const size_t lds1 = 2 * SEQL_BUF + SEQL_ROWS * 4, lds2 = 2 * SEQL_BUF + SEQL_ROWS * 8;
+        SEQL_DISPATCH(seql_dq, lds1, a, nprob, parts, delta);
+        SEQL_DISPATCH(seql_dkv, lds2, a, nprob, parts, (const float*)delta);
+        return lav_check_launch("lav_attention_bwd(long sequence)");
+    }
     const dim3 grid(nprob < 512 ? nprob : 512);
     const size_t lds1 = 2 * SEQ3_IMG + SEQ3_ROWS * 4, lds2 = 2 * SEQ3_IMG + SEQ3_ROWS * 8;
     SEQ3_DISPATCH(seq_dq3, lds1, a, nprob, delta);

@@ -314,25 +314,6 @@ def test_cfg4_swin_large_384_real_widths_forward_vs_oracle():
              "enc_img.swin.layers.0.blocks.1.attn.relative_position_bias_table", "enc_img.swin.layers.1.blocks.0.attn.proj.weight",
              "enc_img.swin.layers.3.blocks.1.mlp.fc2.weight", "enc_img.swin.patch_embed.proj.weight"]
     assert not _subset_report(m, P, names, rel_tol=0.04, cos_tol=0.999)          # measured worst 2.4 % (a relative_position_bias_table)
-    # the pass above read the B x B expansion through the pair map (engine.pair_fused_ok: hidden 768); the materialised-gather
-    # form must give the same logits bit for bit (same GEMM tiles, same operand rows) and the same gradients up to the bf16
-    # rounding of the per-source-row gradient sums
-    from lavender_amd import engine as E
-    assert E.pair_fused_ok(bc["hidden"])
-    g_fused = m.arena().grad.clone()
-    m.arena().zero_grad()
-    E.PAIR_FUSED = False
-    try:
-        out2, _ = m({"img": batch["img"].cuda(), "txt": batch["txt"].cuda(), "mask": batch["mask"].cuda(), "vid": batch["vid"]})
-        CrossEntropyIgnore()(out2.flatten(0, 1), lab.flatten()).backward()
-        torch.cuda.synchronize()
-    finally:
-        E.PAIR_FUSED = True
-    assert torch.equal(out2, out)
-    g_mat = m.arena().grad
-    rel = ((g_fused - g_mat).norm() / g_mat.norm()).item()
-    print("fused vs materialised pair expansion: gradient arena rel diff", rel)
-    assert rel < 5e-3
 
 
 def test_cfg5_retrieval_swin_base_width_vs_oracle():

@@ -5,7 +5,8 @@ import torch
 from lavender_amd import hip as K
 from tools.win_var_probe import bench
 
-for n, L, p in ((160, 282, 0.1), (160, 282, 0.0), (128, 282, 0.1), (32, 282, 0.1), (64, 276, 0.1)):
+SHAPES = ((160, 282, 0.1), (160, 282, 0.0), (128, 282, 0.1), (32, 282, 0.1), (64, 276, 0.1), (40, 757, 0.1), (40, 757, 0.0))   # last two: cfg4 (LAV_SEQL=0: generic kernels)
+for n, L, p in SHAPES:
     heads, Hd = 12, 768
     qkv = torch.randn(n * L, 3 * Hd, device="cuda").bfloat16()
     km = torch.ones(n, L, dtype=torch.int32, device="cuda")
