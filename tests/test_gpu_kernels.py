@@ -418,7 +418,8 @@ def _seq_ref(qkv, mask, n, L, heads):
     return (s.softmax(-1) @ v).transpose(1, 2).reshape(n * L, Hd)
 
 
-@pytest.mark.parametrize("n,L,heads", [(3, 282, 2), (2, 276, 1), (1, 757, 2), (5, 50, 1)])
+@pytest.mark.parametrize("n,L,heads", [(3, 282, 2), (2, 276, 1), (1, 757, 2), (5, 50, 1),
+                                       (3, 300, 1), (2, 768, 1), (44, 757, 2)])     # chunked long-sequence kernels: 2 chunks / full 3 chunks / 264 items on 256 workgroups
 def test_sequence_attention_fwd_bwd(n, L, heads):
     Hd = heads * 64
     qkv = rb(n * L, 3 * Hd)
