@@ -1,5 +1,6 @@
 // Cross-entropy (fused forward + in-place logit gradient) and the flat-arena optimizer kernels.  All HBM-bound.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/lavender_hip.h"
 
 // ---- cross entropy, ignore_index = -1 (agent.py:72; main_pretrain_mlm.py:158-163) ---------------------
@@ -276,6 +277,7 @@ struct AdamArgs {
     float lr[4], wd[4];
     float b1, b2, eps, bc1, bc2, max_norm, grad_div;
     const float* gradsq;
+    int nt;
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
@@ -305,9 +307,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
             const float denom = sqrtf(vv[k]) / sqrtf(a.bc2) + a.eps;
             pp[k] -= (lr / a.bc1) * mm[k] / denom;
         }
-        ((float4*)a.p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-        ((float4*)a.m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-        ((float4*)a.v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (a.nt) {                                       // LAV_NT_STORES & 2 (off by default: measured neutral, 75.1 vs 75.0 ms per step)
+            typedef float lav_f32x4 __attribute__((ext_vector_type(4)));
+            const lav_f32x4 pv = {pp[0], pp[1], pp[2], pp[3]}, mv = {mm[0], mm[1], mm[2], mm[3]}, vv4 = {vv[0], vv[1], vv[2], vv[3]};
+            __builtin_nontemporal_store(pv, (lav_f32x4*)a.p + i);
+            __builtin_nontemporal_store(mv, (lav_f32x4*)a.m + i);
+            __builtin_nontemporal_store(vv4, (lav_f32x4*)a.v + i);
+        } else {
+            ((float4*)a.p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            ((float4*)a.m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            ((float4*)a.v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
         if (a.pb) {
             uint2 w; w.x = pack2(pp[0], pp[1]); w.y = pack2(pp[2], pp[3]);
             ((uint2*)a.pb)[i] = w;
@@ -323,6 +333,8 @@ extern "C" int lav_adamw_step(void* stream, long n, float* p, const float* g, fl
     AdamArgs a;
     a.n = n; a.p = p; a.g = g; a.m = m; a.v = v; a.pb = (bf16_t*)p_bf16;
     a.grp = block_group;
+    static const int nt_stores = getenv("LAV_NT_STORES") ? atoi(getenv("LAV_NT_STORES")) : 1;
+    a.nt = (nt_stores >> 1) & 1;
     for (int k = 0; k < 4; ++k) { a.lr[k] = lr[k]; a.wd[k] = wd[k]; }
     a.b1 = beta1; a.b2 = beta2; a.eps = eps;
     a.bc1 = 1.f - powf(beta1, (float)step); a.bc2 = 1.f - powf(beta2, (float)step);
