@@ -123,6 +123,9 @@ typedef struct lav_ln_bwd_extra {
     float dropout_p; uint32_t seed;
     float* colsum;
     int x_f32;                /* the saved LayerNorm input x is fp32 (see lav_ln_f32) */
+    void* finish_stream;      /* NULL or a hipStream_t: the column reduction that produces dgamma / dbeta / colsum (parameter gradients,
+                                 not needed by the dy -> dx chain) is enqueued THERE, ordered after the row pass by an event; `stream`
+                                 only runs the row pass.  The caller joins finish_stream before it reads those three vectors */
 } lav_ln_bwd_extra;
 
 int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, long lddy, const void* x, long ldx,

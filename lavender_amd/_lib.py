@@ -38,7 +38,7 @@ class LnGather(C.Structure):
 
 class LnBwdExtra(C.Structure):
     _fields_ = [("dx2", vp), ("lddx2", i64), ("row_scale", vp), ("rows_per_group", i32), ("dropout_p", f32),
-                ("seed", u32), ("colsum", vp), ("x_f32", i32)]
+                ("seed", u32), ("colsum", vp), ("x_f32", i32), ("finish_stream", vp)]
 
 
 class LnF32(C.Structure):

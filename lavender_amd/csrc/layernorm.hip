@@ -281,6 +281,26 @@ static float* ln_workspace(void* stream, size_t bytes) {
     return e->ptr;
 }
 
+// ring of scratch buffers for the cross-stream column reduction (see lav_layernorm_bwd)
+struct LnRing { float* ptr; size_t bytes; hipEvent_t produced, consumed; bool used, init; };
+static LnRing g_lnring[8] = {};
+static unsigned g_lnring_next = 0;
+static LnRing* ln_ring_slot(size_t bytes) {
+    LnRing* e = &g_lnring[g_lnring_next++ & 7];
+    if (!e->init) {
+        if (hipEventCreateWithFlags(&e->produced, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->consumed, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        e->init = true;
+    }
+    if (bytes > e->bytes) {
+        if (e->ptr) { (void)hipDeviceSynchronize(); (void)hipFree(e->ptr); e->ptr = nullptr; e->bytes = 0; e->used = false; }
+        size_t want = bytes < ((size_t)8 << 20) ? ((size_t)8 << 20) : bytes + bytes / 2;
+        if (hipMalloc((void**)&e->ptr, want) != hipSuccess) { (void)hipGetLastError(); e->ptr = nullptr; return nullptr; }
+        e->bytes = want;
+    }
+    return e;
+}
+
 static inline void pick_geom(int C, int& G, int& iters) {
     G = C <= 128 ? 16 : (C <= 256 ? 32 : 64);
     iters = (C + G * 8 - 1) / (G * 8);
@@ -354,13 +374,35 @@ extern "C" int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, 
     hipStream_t s = (hipStream_t)stream;
     static const bool use_part = !getenv("LAV_LN_ATOMIC_FLUSH");          // test hook: the old per-block atomics
     const bool any_col = dgamma || dbeta || a.ex.colsum;
-    if (use_part && any_col && grid >= 64) a.part = ln_workspace(stream, (size_t)3 * grid * C * sizeof(float));
+    // The column reduction on another stream (lav_ln_bwd_extra.finish_stream): 78 of these 8-us launches sit in the dy -> dx chain
+    // of a pretrain step otherwise.  Partials go to a ring of scratch buffers; a slot is reused only after the finish kernel that
+    // read it has run (the row-pass stream waits for that event -- eight LayerNorm backwards later, so it never actually waits).
+    hipStream_t fs = (hipStream_t)a.ex.finish_stream;
+    LnRing* slot = nullptr;
+    if (use_part && any_col && grid >= 64) {
+        if (fs && fs != s) {
+            slot = ln_ring_slot((size_t)3 * grid * C * sizeof(float));
+            if (slot) {
+                if (slot->used) (void)hipStreamWaitEvent(s, slot->consumed, 0);
+                a.part = slot->ptr;
+            }
+        }
+        if (!a.part) a.part = ln_workspace(stream, (size_t)3 * grid * C * sizeof(float));
+    }
 #define K_(G_, I_, X_) hipLaunchKernelGGL((ln_bwd_kernel<G_, I_, X_>), dim3(grid), dim3(256), lds, s, a);
     const bool x32 = a.ex.x_f32 != 0;
     LN_DISPATCH(K_, x32)
 #undef K_
-    if (a.part)
-        hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((C + 31) / 32, 3), dim3(256), 0, s, (const float*)a.part, grid, C, dgamma, dbeta, a.ex.colsum);
+    if (a.part) {
+        hipStream_t rs = s;
+        if (slot) {
+            (void)hipEventRecord(slot->produced, s);
+            (void)hipStreamWaitEvent(fs, slot->produced, 0);
+            rs = fs;
+        }
+        hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((C + 31) / 32, 3), dim3(256), 0, rs, (const float*)a.part, grid, C, dgamma, dbeta, a.ex.colsum);
+        if (slot) { (void)hipEventRecord(slot->consumed, fs); slot->used = true; }
+    }
     return lav_check_launch("lav_layernorm_bwd");
 }
 

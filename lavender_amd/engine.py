@@ -74,6 +74,17 @@ def dw_gemm(A, Bm, M, N, Kd, **kw):
             t.record_stream(side)
 
 
+_LN_SIDE = os.environ.get("LAV_LN_FINISH_SIDE", "0") != "0"     # measured neutral on the cfg2 step (76.3 vs 76.3-76.6 ms): off by default
+
+
+def ln_bwd(dy, *args, **kw):
+    """K.layernorm_bwd with the column reduction (dgamma / dbeta / bias column sums: parameter gradients) on the weight-gradient
+    stream -- everything that reads those gradients already joins that stream (dw_join, the reducer's range events)."""
+    if _DW_SIDE and _LN_SIDE:
+        kw["finish_stream"] = dw_stream(dy.device)
+    return K.layernorm_bwd(dy, *args, **kw)
+
+
 def dw_join(device=None):
     """main stream waits for every weight-gradient kernel issued so far (before the gradients are read)."""
     for dev, st in _dw_streams.items():
@@ -136,7 +147,7 @@ class PatchEmbedFn(torch.autograd.Function):
         cols, y, mean, rstd = ctx.saved_tensors
         M, E = y.shape
         dx = dx.contiguous()
-        dy = K.layernorm_bwd(dx, y, M, E, mod.norm.weight.data, mean, rstd, G(mod.norm.weight), G(mod.norm.bias),
+        dy = ln_bwd(dx, y, M, E, mod.norm.weight.data, mean, rstd, G(mod.norm.weight), G(mod.norm.bias),
                              colsum=G(mod.proj.bias))
         dw_gemm(dy, cols, E, 96, M, out=G(mod.proj.weight).view(E, 96), accumulate=True, splits=K.splits_for(E, 96, M))
         dw_join(dy.device)                                # last stage of the backward: every gradient is final on the main stream
@@ -213,7 +224,7 @@ class SwinBlockFn(torch.autograd.Function):
         dw_gemm(dh, y2, 4 * C, C, M, out=G(mlp.fc1.weight), accumulate=True, splits=K.splits_for(4 * C, C, M))
         d_y2 = K.gemm(0, dh, W16T(mlp.fc1.weight), M, C, 4 * C)
         del dh
-        d_mid = K.layernorm_bwd(d_y2, x_mid, M, C, blk.norm2.weight.data, mean2, rstd2, G(blk.norm2.weight), G(blk.norm2.bias),
+        d_mid = ln_bwd(d_y2, x_mid, M, C, blk.norm2.weight.data, mean2, rstd2, G(blk.norm2.weight), G(blk.norm2.bias),
                                 add_in=dy)
         # --- attention branch: x_mid = x + s * proj(attn(qkv(LN1(x)))) ---------------------------------
         dw_gemm(d_mid, ao, C, C, M, out=G(a.proj.weight), accumulate=True, k_keep=dp_attn, k_rows_per_group=rpg,
@@ -241,7 +252,7 @@ class SwinBlockFn(torch.autograd.Function):
         d_y1 = K.gemm(0, dqkv, W16T(a.qkv.weight), Ma, C, 3 * C)
         if pad is not None:
             d_y1 = K.gather_rows(d_y1, pad[3], M, C)
-        dx = K.layernorm_bwd(d_y1, x, M, C, blk.norm1.weight.data, mean1, rstd1, G(blk.norm1.weight), G(blk.norm1.bias),
+        dx = ln_bwd(d_y1, x, M, C, blk.norm1.weight.data, mean1, rstd1, G(blk.norm1.weight), G(blk.norm1.bias),
                              add_in=d_mid)
         if ctx.notify and ctx.arena is not None:
             ctx.arena.notify(ctx.notify)                 # data-parallel reducer: this stage's gradient range is final
@@ -277,7 +288,7 @@ class PatchMergeFn(torch.autograd.Function):
         dout = dout.contiguous()
         dw_gemm(dout, y, 2 * C, 4 * C, rows, out=G(mod.reduction.weight), accumulate=True, splits=K.splits_for(2 * C, 4 * C, rows))
         d_y = K.gemm(0, dout, W16T(mod.reduction.weight), rows, 4 * C, 2 * C)
-        dx = K.layernorm_bwd(d_y, x, rows, 4 * C, mod.norm.weight.data, mean, rstd, G(mod.norm.weight), G(mod.norm.bias),
+        dx = ln_bwd(d_y, x, rows, 4 * C, mod.norm.weight.data, mean, rstd, G(mod.norm.weight), G(mod.norm.bias),
                              gather=(H, W, C))
         if ctx.pad is not None:
             dx = K.gather_rows(dx, ctx.pad[3], len(ctx.pad[3]), C)
@@ -300,7 +311,7 @@ class LayerNormFn(torch.autograd.Function):
         mod = ctx.mod
         x, mean, rstd = ctx.saved_tensors
         M, C = x.shape
-        dx = K.layernorm_bwd(dy.contiguous(), x, M, C, mod.weight.data, mean, rstd, G(mod.weight), G(mod.bias))
+        dx = ln_bwd(dy.contiguous(), x, M, C, mod.weight.data, mean, rstd, G(mod.weight), G(mod.bias))
         return None, dx, None, None
 
 
@@ -526,7 +537,7 @@ class BertLayerFn(torch.autograd.Function):
         dy = dy.contiguous()
         # out = LN(pre2), pre2 = x1 + dropout(dense(h))
         d_dense2 = torch.empty((R, Hd), dtype=bf16, device=x.device)
-        d_pre2 = K.layernorm_bwd(dy, pre2, R, Hd, outp.LayerNorm.weight.data, mean2, rstd2, G(outp.LayerNorm.weight),
+        d_pre2 = ln_bwd(dy, pre2, R, Hd, outp.LayerNorm.weight.data, mean2, rstd2, G(outp.LayerNorm.weight),
                                  G(outp.LayerNorm.bias), dx2=d_dense2, dropout_p=p, seed=s2, colsum=G(outp.dense.bias))
         dw_gemm(d_dense2, h, Hd, F, R, out=G(outp.dense.weight), accumulate=True, splits=K.splits_for(Hd, F, R))
         dh = K.gemm(0, d_dense2, W16T(outp.dense.weight), R, F, Hd, gelu_in=h_pre, gelu_in_is_grad=_GQ, colsum=G(inter.dense.bias))
@@ -535,7 +546,7 @@ class BertLayerFn(torch.autograd.Function):
         del dh
         # x1 = LN(pre1), pre1 = x + dropout(dense(ctx))
         d_dense1 = torch.empty_like(d_dense2) if _DW_SIDE else d_dense2     # the side stream may still read d_dense2
-        d_pre1 = K.layernorm_bwd(d_x1, pre1, R, Hd, ao.LayerNorm.weight.data, mean1, rstd1, G(ao.LayerNorm.weight),
+        d_pre1 = ln_bwd(d_x1, pre1, R, Hd, ao.LayerNorm.weight.data, mean1, rstd1, G(ao.LayerNorm.weight),
                                  G(ao.LayerNorm.bias), dx2=d_dense1, dropout_p=p, seed=s1, colsum=G(ao.dense.bias))
         dw_gemm(d_dense1, cx, Hd, Hd, R, out=G(ao.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))
         d_cx = K.gemm(0, d_dense1, W16T(ao.dense.weight), R, Hd, Hd)
@@ -618,7 +629,7 @@ class MLMHeadFn(torch.autograd.Function):
         # product is unchanged and the GEMM can take the large-tile path
         Kv = d2.stride(0) if (d2.stride(0) % 64 == 0 and d2.stride(0) - V < 64) else V
         d_tn = K.gemm(0, d2, W16T(dec.weight), R, Hd, Kv, splits=K.splits_nn(R, Hd, Kv))   # W^T rows are padded to 64 with zeros
-        d_t = K.layernorm_bwd(d_tn, t, R, Hd, tr.LayerNorm.weight.data, mean, rstd, G(tr.LayerNorm.weight), G(tr.LayerNorm.bias))
+        d_t = ln_bwd(d_tn, t, R, Hd, tr.LayerNorm.weight.data, mean, rstd, G(tr.LayerNorm.weight), G(tr.LayerNorm.bias))
         d_tpre = torch.empty((R, Hd), dtype=bf16, device=d_t.device)
         K.scale_mask_rows(d_t, R, Hd, out=d_tpre, colsum=G(tr.dense.bias), gelu_in=t_pre)
         dw_gemm(d_tpre, x2, Hd, Hd, R, out=G(tr.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))

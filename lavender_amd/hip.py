@@ -136,7 +136,9 @@ def layernorm_fwd(x, rows, Cn, gamma, beta, eps, gather=None, out=None, want_sta
 
 
 def layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dgamma, dbeta, gather=None, add_in=None, dx=None, dx2=None,
-                  row_scale=None, rows_per_group=1, dropout_p=0.0, seed=0, colsum=None):
+                  row_scale=None, rows_per_group=1, dropout_p=0.0, seed=0, colsum=None, finish_stream=None):
+    """finish_stream (a torch.cuda.Stream): dgamma / dbeta / colsum are completed there (lav_ln_bwd_extra.finish_stream); the
+    caller joins it before reading them."""
     dev = dy.device
     if dx is None:
         dx = torch.empty((rows * 4, Cn // 4) if gather is not None else (rows, Cn), dtype=bf16, device=dev)
@@ -144,8 +146,9 @@ def layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dgamma, dbeta, gather=None
     lddx = gather[2] if gather is not None else _ld(dx)
     ex = None
     x32 = x.dtype == torch.float32
-    if dx2 is not None or colsum is not None or x32:
+    if dx2 is not None or colsum is not None or x32 or finish_stream is not None:
         s = L.LnBwdExtra()
+        s.finish_stream = finish_stream.cuda_stream if finish_stream is not None else None
         s.x_f32 = int(x32)
         s.dx2 = _p(dx2)
         s.lddx2 = _ld(dx2) if dx2 is not None else 0

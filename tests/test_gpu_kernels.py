@@ -328,6 +328,34 @@ def test_gemm_reads_a_and_residual_through_a_row_map():
     close(y0, ref, atol=3e-2, rtol=2e-2, what="gathered GEMM vs fp32 reference")
 
 
+def test_layernorm_backward_column_reduction_on_another_stream():
+    """lav_ln_bwd_extra.finish_stream: dgamma / dbeta / colsum completed on a second stream give the same values; the ring of
+    scratch buffers survives more calls than it has slots."""
+    rows, Cn = 45120 // 8, 768
+    x, dy = rb(rows, Cn, seed=1), rb(rows, Cn, seed=2)
+    gamma = torch.randn(Cn, device="cuda")
+    mean = x.float().mean(-1); rstd = (x.float().var(-1, unbiased=False) + 1e-5).rsqrt()
+    side = torch.cuda.Stream()
+    ref = None
+    for it in range(11):
+        dg, db = torch.zeros(Cn, device="cuda"), torch.zeros(Cn, device="cuda")
+        cs = torch.zeros(Cn, device="cuda")
+        dx2 = torch.empty_like(x)
+        fs = side if it else None
+        side.wait_stream(torch.cuda.current_stream())             # the zero-filled outputs above
+        dx = K().layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dg, db, dx2=dx2, dropout_p=0.1, seed=5, colsum=cs, finish_stream=fs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        cur = (dx.clone(), dg.clone(), db.clone(), cs.clone())
+        if ref is None:
+            ref = cur
+            assert float(dg.abs().sum()) > 0 and float(cs.abs().sum()) > 0
+        else:
+            assert torch.equal(cur[0], ref[0])
+            for a_, b_ in zip(cur[1:], ref[1:]):
+                assert torch.allclose(a_, b_, rtol=1e-5, atol=1e-4)    # atomics: summation order of the 24 column blocks
+
+
 # ---------------------------------------------------------------------------------------------- attention
 def _win_ref(qkv, table, B, D, H, W, C, heads, win, shift, cfg):
     """window attention of video_swin.py:145-170,218-239 on a (tokens, 3C) qkv tensor via the oracle helpers."""
