@@ -196,6 +196,8 @@ def main():
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(local_rank)
+        if os.environ.get("LAV_MAIN_HIPRI", "0") != "0":      # probe hook: the dy -> dx chain on a high-priority stream (the weight-gradient stream stays normal)
+            torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl" if use_cuda else "gloo", init_method="env://")

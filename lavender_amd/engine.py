@@ -47,6 +47,7 @@ _DW_SIDE = os.environ.get("LAV_DW_STREAM", "1") != "0"
 _GQ = 2 if os.environ.get("LAV_GELU_GRAD_U8", "0") != "0" else 1          # GELU' storage: 1 = bf16 (default), 2 = one byte per element (measured 0.8 ms/step SLOWER: the pack / unpack VALU work outweighs the bytes)
 _GQ_DT = torch.uint8 if _GQ == 2 else torch.bfloat16
 _dw_streams = {}
+_DW_PRIORITY = int(os.environ.get("LAV_DW_PRIORITY", "0"))      # probe hook: HIP priority of the weight-gradient stream (positive = lower than the main stream)
 # fp32 residual stream of the post-LN fusion encoder: the pre-LN sums x + dropout(dense(.)) and the LayerNorm outputs that
 # feed the next residual add stay fp32 (the GEMM operands are the bf16 copies).  Measured on the oracle with bf16 rounding
 # injected (tests/bf16_error_budget.py): this halves the logit error of the full-width model (mean 5.5e-3 -> 2.5e-3, max
@@ -57,7 +58,7 @@ STREAM32 = os.environ.get("LAV_STREAM32", "1") != "0"
 def dw_stream(device):
     st = _dw_streams.get(device)
     if st is None:
-        st = _dw_streams[device] = torch.cuda.Stream(device=device)
+        st = _dw_streams[device] = torch.cuda.Stream(device=device, priority=_DW_PRIORITY)
     return st
 
 

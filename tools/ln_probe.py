@@ -30,3 +30,19 @@ for rows, C, extra in ((31360, 512, False), (31360, 512, True), (36096, 768, Tru
         nt = 4
     us = t(f)
     print(f"rows={rows:6d} C={C:4d} extra={extra}: {us:6.1f} us  {nt*rows*C*2/us/1e3:6.0f} GB/s;  fwd {t(lambda: K.layernorm_fwd(x, rows, C, g, b, 1e-5)):5.1f} us")
+
+# Swin-L 384^2 (cfg4, B = 8) shapes, incl. the PatchMerging gather form (rows = merged rows, C = 4 * C0)
+print("cfg4 shapes:")
+for rows, C, gather in ((368640, 192, None), (92160, 768, (96, 96, 192)), (92160, 384, None), (23040, 1536, (48, 48, 384)), (23040, 768, None),
+                        (5760, 3072, (24, 24, 768)), (5760, 1536, None)):
+    if gather is None:
+        x = torch.randn(rows, C, device="cuda").to(bf)
+    else:
+        x = torch.randn(rows * 4, C // 4, device="cuda").to(bf)
+    dy = torch.randn(rows, C, device="cuda").to(bf)
+    g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
+    y, mean, rstd = K.layernorm_fwd(x, rows, C, g, b, 1e-5, gather=gather)
+    dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
+    us = t(lambda: K.layernorm_bwd(dy, x, rows, C, g, mean, rstd, dg, db, gather=gather))
+    uf = t(lambda: K.layernorm_fwd(x, rows, C, g, b, 1e-5, gather=gather))
+    print(f"rows={rows:6d} C={C:4d} gather={gather}: bwd {us:7.1f} us {3*rows*C*2/us/1e3:6.0f} GB/s;  fwd {uf:6.1f} us {2*rows*C*2/uf/1e3:6.0f} GB/s")
