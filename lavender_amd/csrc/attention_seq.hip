@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void seq_fwd3(AttnArgs a, int nprob) {
 #pragma unroll
                 for (int r = 3; r < 15; r += 2) mx = smax3(mx, s[r], s[r + 1]);
                 mx = fmaxf(mx, s[15]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+                mx = xhalf_max(mx) * sc;
                 if (__any(mx > m_run)) {
                     const float m_new = fmaxf(m_run, mx);
                     const float alpha = fast_exp2(m_run - m_new);   // m_run = -inf -> 0; a fully masked prefix keeps m = -inf
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void seq_fwd3(AttnArgs a, int nprob) {
                     soft(t + 1, sb);
                 }
             }
-            const float l_tot = __shfl(lacc[0], j, 64);
+            const float l_tot = lower_half(lacc[0]);
             const float inv_l = l_tot > 0.f ? 1.f / l_tot : 0.f;
             if (q_ok) {
                 bf16_t* op = a.o_w + ((long)prob * N + q) * C + head * HD;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void seq_dq3(AttnArgs a, int nprob, float* 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dl = fmaf(gf[e], of[e], dl);
             }
-            dl += __shfl_xor(dl, 32, 64);
+            dl = xhalf_add(dl);
             const float nl = q_ok ? -a.lse[(long)p * a.Npad + q] : -INFINITY;   // padded query: P = 0
             if (q_ok && hi == 0) delta_out[(long)p * a.Npad + q] = dl;
             const float ndl = -dl;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(512) void seql_fwd(AttnArgs a, int nprob, int parts
 #pragma unroll
                     for (int r = 3; r < 15; r += 2) mx = smax3(mx, s[r], s[r + 1]);
                     mx = fmaxf(mx, s[15]);
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+                    mx = xhalf_max(mx) * sc;
                     if (__any(mx > m_run)) {
                         const float m_new = fmaxf(m_run, mx);
                         const float alpha = fast_exp2(m_run - m_new);
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(512) void seql_fwd(AttnArgs a, int nprob, int parts
             sdma_wait_all();
             __syncthreads();
         }
-        const float l_tot = __shfl(lacc[0], j, 64);
+        const float l_tot = lower_half(lacc[0]);
         const float inv_l = l_tot > 0.f ? 1.f / l_tot : 0.f;
         if (q_ok) {
             bf16_t* op = a.o_w + ((long)prob * N + q) * C + head * HD;
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(512) void seql_dq(AttnArgs a, int nprob, int parts,
 #pragma unroll
             for (int e = 0; e < 8; ++e) dl = fmaf(gf[e], of[e], dl);
         }
-        dl += __shfl_xor(dl, 32, 64);
+        dl = xhalf_add(dl);
         const float nl = q_ok ? -a.lse[(long)p * a.Npad + q] : -INFINITY;
         if (q_ok && hi == 0) delta_out[(long)p * a.Npad + q] = dl;
         const float ndl = -dl;

@@ -86,7 +86,7 @@ __device__ __forceinline__ bf16x8 ident_frag(int slab, int j, int hi) {
 }
 
 __device__ __forceinline__ float xhalf_sum(float v) {        // v + (the other 32-lane half's v of the same column)
-    return v + __shfl_xor(v, 32, 64);
+    return xhalf_add(v);
 }
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512) void win_fwd3(AttnArgs a, int bsplit) {
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mx = max3f(mx, s[r], s[r + 1]);
             mx = fmaxf(mx, s[15]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+            mx = xhalf_max(mx) * sc;
             if (__any(mx > m_run)) {
                 const float m_new = fmaxf(m_run, mx);
                 const float alpha = fast_exp2(m_run - m_new);
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(512) void win_fwd3(AttnArgs a, int bsplit) {
             const float nm = -m_run;
             uint32_t pk[8];
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack2(fast_exp2(fmaf(s[r], sc, nm)), fast_exp2(fmaf(s[r + 1], sc, nm)));
+            for (int r = 0; r < 16; r += 2) { const lav_f2 e = fma2(s[r], s[r + 1], sc, nm, nm); pk[r >> 1] = pack2(fast_exp2(e.x), fast_exp2(e.y)); }
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
                 Frag pf; pf.u = make_uint4(pk[4 * sl], pk[4 * sl + 1], pk[4 * sl + 2], pk[4 * sl + 3]);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void win_fwd3(AttnArgs a, int bsplit) {
             }
         }
         // row 0 of the l tile sits in register 0 of the lower half-wave
-        const float l_tot = __shfl(lacc[0], j, 64);
+        const float l_tot = lower_half(lacc[0]);
         const float inv_l = l_tot > 0.f ? 1.f / l_tot : 0.f;
         if (q_ok) {
             const long row = (long)b * a.tps + qrel;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(512) void win_dq3(AttnArgs a, int bsplit, float* nd
             uint32_t dk[8];
 #pragma unroll
             for (int r = 0; r < 16; r += 2)
-                dk[r >> 1] = pack2(fast_exp2(fmaf(s[r], sc, nl)) * dp[r], fast_exp2(fmaf(s[r + 1], sc, nl)) * dp[r + 1]);
+                { const lav_f2 e = fma2(s[r], s[r + 1], sc, nl, nl); const lav_f2 d = mul2(fast_exp2(e.x), fast_exp2(e.y), dp[r], dp[r + 1]); dk[r >> 1] = pack2(d.x, d.y); }
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
                 Frag df; df.u = make_uint4(dk[4 * sl], dk[4 * sl + 1], dk[4 * sl + 2], dk[4 * sl + 3]);
@@ -490,8 +490,10 @@ __global__ __launch_bounds__(512) void win_dkv3(AttnArgs a, int bsplit, const fl
                 uint32_t pk[8], dsk[8];
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    float p0 = fast_exp2(fmaf(s[r], sc, -nls[r])), p1 = fast_exp2(fmaf(s[r + 1], sc, -nls[r + 1]));
-                    float d0 = p0 * dp[r], d1 = p1 * dp[r + 1];
+                    const lav_f2 e2 = fma2(s[r], s[r + 1], sc, -nls[r], -nls[r + 1]);
+                    float p0 = fast_exp2(e2.x), p1 = fast_exp2(e2.y);
+                    const lav_f2 dd = mul2(p0, p1, dp[r], dp[r + 1]);
+                    float d0 = dd.x, d1 = dd.y;
                     if (qt == NT - 1) {                      // padded query rows of the last tile: their lse / delta slots were never
                         const int qq = q0 + tile_row(r, hi);     // written (selects, not multiplies: the garbage may be inf / NaN)
                         if (qq >= N) { p0 = 0.f; d0 = 0.f; }
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(512) void win_dbias3(AttnArgs a, int bsplit, const 
                 uint32_t dk[8];
 #pragma unroll
                 for (int r = 0; r < 16; r += 2)
-                    dk[r >> 1] = pack2(fast_exp2(fmaf(s[r], sc, nl)) * dp[r], fast_exp2(fmaf(s[r + 1], sc, nl)) * dp[r + 1]);
+                    { const lav_f2 e = fma2(s[r], s[r + 1], sc, nl, nl); const lav_f2 d = mul2(fast_exp2(e.x), fast_exp2(e.y), dp[r], dp[r + 1]); dk[r >> 1] = pack2(d.x, d.y); }
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
                     Frag df; df.u = make_uint4(dk[4 * sl], dk[4 * sl + 1], dk[4 * sl + 2], dk[4 * sl + 3]);

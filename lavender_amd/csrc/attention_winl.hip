@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512) void winl_fwd(AttnArgs a, int nwin, int QS, Wl
 #pragma unroll
                 for (int r = 3; r < 15; r += 2) mx = wmax3(mx, s[r], s[r + 1]);
                 mx = fmaxf(mx, s[15]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = xhalf_max(mx);
                 if (__any(mx > m_run)) {
                     const float m_new = fmaxf(m_run, mx);
                     const float alpha = fast_exp2(m_run - m_new);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512) void winl_fwd(AttnArgs a, int nwin, int QS, Wl
                     soft(t + 1, sb);
                 }
             }
-            const float l_tot = __shfl(lacc[0], j, 64);
+            const float l_tot = lower_half(lacc[0]);
             const float inv_l = l_tot > 0.f ? 1.f / l_tot : 0.f;
             if (q_ok) {
                 bf16_t* op = a.o_w + qrow * C + w.head * HD;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) void winl_dq(AttnArgs a, int nwin, int QS, WlT
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dl = fmaf(gf[e], of[e], dl);
             }
-            dl += __shfl_xor(dl, 32, 64);
+            dl = xhalf_add(dl);
             const float nl = q_ok ? -a.lse[w.p * a.Npad + q] : -INFINITY;     // padded query: P = 0
             if (q_ok && hi == 0) delta_out[w.p * a.Npad + q] = dl;
             f32x16 ndl;

@@ -53,6 +53,27 @@ __device__ __forceinline__ void comb_tile(const bf16_t* base, int tile, int lane
 
 __device__ __forceinline__ int tile_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// Cross-half exchange of a wave64 (lane j <-> lane j + 32) without the LDS round trip of ds_bpermute_b32: v_permlane32_swap_b32
+// (gfx950) returns the lower half's values in every lane (lo) and the upper half's values in every lane (hi).
+__device__ __forceinline__ void half_swap(float v, float& lo, float& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xhalf_max(float v) { float lo, hi; half_swap(v, lo, hi); return fmaxf(lo, hi); }
+__device__ __forceinline__ float xhalf_add(float v) { float lo, hi; half_swap(v, lo, hi); return lo + hi; }
+__device__ __forceinline__ float lower_half(float v) { float lo, hi; half_swap(v, lo, hi); return lo; }
+
+// two exponent arguments with ONE v_pk_fma_f32 (packed fp32: both halves of the 64-bit register pair in one issue slot)
+typedef float lav_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lav_f2 fma2(float a0, float a1, float b, float c0, float c1) {
+    const lav_f2 a = {a0, a1}, bb = {b, b}, c = {c0, c1};
+    return __builtin_elementwise_fma(a, bb, c);
+}
+__device__ __forceinline__ lav_f2 mul2(float a0, float a1, float b0, float b1) {
+    const lav_f2 a = {a0, a1}, b = {b0, b1};
+    return a * b;
+}
+
 struct TokInfo { int row; int code; int region; };
 
 // window w, in-window index i  ->  global token row (un-rolled tensor), bias code, shift region
