@@ -701,6 +701,9 @@ static void wl_lds(Kn k, size_t bytes) {
 
 static const bool lav_winl_on = getenv("LAV_WINL") ? atoi(getenv("LAV_WINL")) != 0 : true;   // probe hook: 0 = generic kernels
 
+static int lav_winl_parts = 0;                             // test hook: force the number of query parts per problem (0 = by problem count)
+extern "C" int lav_winl_select(int parts) { const int old = lav_winl_parts; lav_winl_parts = parts; return old; }
+
 static WlTab wl_tab(const AttnArgs& a) {
     const lav_attn_desc& d = a.d;
     const int i = a.N - 1;                                   // codes grow with the slot index: the last slot has the largest
@@ -712,6 +715,7 @@ static WlTab wl_tab(const AttnArgs& a) {
 }
 
 bool winl_supported(const AttnArgs& a) {
+    if (lav_winl_parts < 0) return false;                     // test hook: lav_winl_select(-1) routes large windows to the generic kernels
     if (!(lav_winl_on && a.d.mode == 0 && !a.d.comb && a.N <= WL_ROWS)) return false;
     const double qkv_bytes = (double)a.d.B * a.tps * 3.0 * a.C * 2.0;             // DMA offsets are 32-bit
     const WlTab t = wl_tab(a);
@@ -719,8 +723,6 @@ bool winl_supported(const AttnArgs& a) {
            (size_t)t.n * 4 + WLB_MAIN + 384 * 4 + 512 <= 160 * 1024;
 }
 
-static int lav_winl_parts = 0;                             // test hook: force the number of query parts per problem (0 = by problem count)
-extern "C" int lav_winl_select(int parts) { const int old = lav_winl_parts; lav_winl_parts = parts; return old; }
 static int wl_parts(int problems) { return lav_winl_parts > 0 ? lav_winl_parts : problems >= 1024 ? 1 : 3; }
 
 int winl_fwd_launch(void* stream, const AttnArgs& a, int nwin) {

@@ -390,6 +390,7 @@ def _win_ref(qkv, table, B, D, H, W, C, heads, win, shift, cfg):
     (2, 5, 12, 24, 32, 1, (5, 12, 12), (0, 0, 0), (8, 12, 12)),   # N=720 unshifted
     (90, 5, 12, 12, 32, 1, (5, 12, 12), (0, 0, 0), (8, 12, 12)),  # N=720, 270 items on 256 workgroups (persistent walk)
     (2, 5, 24, 24, 64, 2, (5, 12, 12), (0, 6, 6), (8, 12, 12), 1),  # N=720 shifted, whole problems per workgroup (the many-problem form)
+    (1, 16, 14, 14, 32, 1, (8, 7, 7), (4, 3, 3), None, -1),       # N=392 on the GENERIC kernels (what windows of more than 768 tokens use)
 ])
 def test_window_attention_fwd_bwd(case):
     B, D, H, W, C, heads, win, shift = case[:8]
@@ -447,7 +448,8 @@ def _seq_ref(qkv, mask, n, L, heads):
 
 
 @pytest.mark.parametrize("n,L,heads", [(3, 282, 2), (2, 276, 1), (1, 757, 2), (5, 50, 1),
-                                       (3, 300, 1), (2, 768, 1), (44, 757, 2)])     # chunked long-sequence kernels: 2 chunks / full 3 chunks / 264 items on 256 workgroups
+                                       (3, 300, 1), (2, 768, 1), (44, 757, 2),      # chunked long-sequence kernels: 2 chunks / full 3 chunks / 264 items on 256 workgroups
+                                       (1, 800, 1)])                               # beyond 768 tokens: the generic kernels
 def test_sequence_attention_fwd_bwd(n, L, heads):
     Hd = heads * 64
     qkv = rb(n * L, 3 * Hd)
