@@ -10,7 +10,14 @@ bf16 = torch.bfloat16
 _seed_counter = [0x1234567]
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _s():
+    # the current torch stream's hipStream_t; the raw getter costs ~0.3 us against 2.7 us for torch.cuda.current_stream().cuda_stream
+    # (~1500 calls per training step)
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

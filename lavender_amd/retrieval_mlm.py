@@ -55,8 +55,8 @@ class Agent_Retrieval_MLM(Agent_Base):
         super().__init__(args, model)
         self.log = {'ls_tr': [], 'ac_vl': [], 'ac_ts': []}
 
-    def step(self, batch, is_train):
-        """main_retrieval_mlm.py:99-118."""
+    def step(self, batch, is_train, sync=True):
+        """main_retrieval_mlm.py:99-118.  sync=False returns the training loss as a device scalar (no host round trip per step)."""
         self.model.train() if is_train else self.model.eval()
         with torch.set_grad_enabled(is_train):
             out, ans = self.forward_step(batch)
@@ -65,7 +65,7 @@ class Agent_Retrieval_MLM(Agent_Base):
                 ans = ans.flatten(0, len(ans.shape) - 1)
                 ls = self.loss_func(out, ans, out.shape[0] // batch["txt"].shape[1])
                 self.backward_step(ls)
-                return ls.item()
+                return ls.item() if sync else ls.detach()
         _B = len(batch["vid"])
         p_true = out[:, :, self.true_token_id].float()
         p_false = out[:, :, self.false_token_id].float()
