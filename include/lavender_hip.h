@@ -75,6 +75,10 @@ typedef struct lav_gemm_epilogue {
                                  (main_retrieval_mlm.py:62-87, main_pretrain_mlm.py:74-111): the (pairs, L, H) fusion input is never
                                  materialised, the first layer's QKV GEMM reads the video / text rows of each pair through this map */
     const int* res_rowmap;    /* residual row of output row m is res_rowmap[m] (same use: the first layer's residual is the un-expanded input) */
+    const float* res_ln_mean; /* non-NULL (with residual_f32 and an fp32 output): `residual` holds the PRE-LayerNorm rows and the epilogue adds */
+    const float* res_ln_rstd; /* LayerNorm(residual) = (r - mean[row]) * rstd[row] * gamma[col] + beta[col] -- the same arithmetic as          */
+    const float* res_ln_gamma;/* lav_layernorm_fwd, so the fp32 copy of a LayerNorm output that only feeds the next residual add              */
+    const float* res_ln_beta; /* (post-LN BERT: BertSelfOutput / BertOutput) is never written: 138 MB per LayerNorm at the cfg2 shape         */
 } lav_gemm_epilogue;
 
 int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B, long ldb,

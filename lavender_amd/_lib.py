@@ -29,7 +29,8 @@ class GemmEpilogue(C.Structure):
                 ("dropout_p", f32), ("seed", u32), ("row_scale", vp), ("rows_per_group", i32), ("residual", vp),
                 ("ldr", i64), ("colsum", vp), ("alpha", f32), ("out_mode", i32), ("k_keep", vp),
                 ("k_rows_per_group", i32), ("rowsum_a", vp), ("preact_is_grad", i32), ("gelu_in_is_grad", i32),
-                ("residual_f32", i32), ("a_rowmap", vp), ("res_rowmap", vp)]
+                ("residual_f32", i32), ("a_rowmap", vp), ("res_rowmap", vp),
+                ("res_ln_mean", vp), ("res_ln_rstd", vp), ("res_ln_gamma", vp), ("res_ln_beta", vp)]
 
 
 class LnGather(C.Structure):

@@ -207,6 +207,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         for (int x = 0; x < 8; ++x)
             if (x < ncols) bias[x] = e.bias[gcol + x];
     }
+    // LayerNorm of the residual rows (res_ln_*): this thread's 8 columns of gamma / beta, once
+    float lng[8] = {1, 1, 1, 1, 1, 1, 1, 1}, lnb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool has_resln = (GEN || (F & EF_O32)) && (F & EF_RES) && e.residual && e.residual_f32 && e.res_ln_mean;
+    if (has_resln && ncols > 0) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+            if (x < ncols) { lng[x] = e.res_ln_gamma[gcol + x]; lnb[x] = e.res_ln_beta[gcol + x]; }
+    }
     // specialised variants are only dispatched when N % 8 == 0: a chunk is whole or outside the matrix, so past the
     // "outside" test every access is a full 16-byte one (compile-time) -- the preloads below run BEFORE that test
     const bool full = GEN ? ncols == 8 : true;
@@ -332,6 +340,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             if (e.residual_f32) {
                 if (full) { *(uint4*)&h[0] = pre_r[u]; *(uint4*)&h[4] = pre_r2[u]; }
                 else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? ((const float*)e.residual)[rrow * e.ldr + gcol + x] : 0.f;
+                if (has_resln) {                          // the residual is a pre-LayerNorm row: add LayerNorm(row) (ln_fwd_kernel's arithmetic)
+                    const long lrow = e.res_rowmap ? e.res_rowmap[grow] : grow;
+                    const float mu = e.res_ln_mean[lrow], rs = e.res_ln_rstd[lrow];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) h[x] = (h[x] - mu) * rs * lng[x] + lnb[x];
+                }
             } else if (full) unpack8(pre_r[u], h);
             else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? bf2f(p[x]) : 0.f;
 #pragma unroll

@@ -53,6 +53,10 @@ _DW_PRIORITY = int(os.environ.get("LAV_DW_PRIORITY", "0"))      # probe hook: HI
 # injected (tests/bf16_error_budget.py): this halves the logit error of the full-width model (mean 5.5e-3 -> 2.5e-3, max
 # 3.6e-2 -> 1.6e-2); the same change on the pre-LN Swin stream changes nothing, so the video side stays bf16.
 STREAM32 = os.environ.get("LAV_STREAM32", "1") != "0"
+# The fp32 copy of a LayerNorm output only ever feeds the NEXT residual add, so it is not written: that GEMM epilogue takes the
+# saved pre-LayerNorm rows + (mean, rstd, gamma, beta) and adds LayerNorm(rows) itself (lav_gemm_epilogue.res_ln_*; same
+# arithmetic, same bits).  138 MB less written per LayerNorm at the cfg2 shape.  LAV_RESLN=0 restores the fp32 LayerNorm output.
+RESLN = STREAM32 and os.environ.get("LAV_RESLN", "1") != "0"
 
 
 def dw_stream(device):
@@ -484,7 +488,10 @@ class BertLayerFn(torch.autograd.Function):
         pair = (rowmap, start, order) (first layer only): x holds the UN-EXPANDED rows [video rows of every clip ; text rows of
         every text] and row r of the n * L pair rows is x[rowmap[r]] -- the QKV GEMM and the residual add read x through the map,
         the (n, L, H) expansion of main_retrieval_mlm.py:62-87 / main_pretrain_mlm.py:74-111 never exists; (start, order) is the
-        map's inverse for the backward."""
+        map's inverse for the backward.
+        With RESLN, x32 is not an fp32 tensor but the tuple (pre, mean, rstd, gamma, beta) of the LayerNorm that produced x, and
+        the second return value is that tuple for this layer's output LayerNorm (pre2, mean2, rstd2 as extra non-differentiable
+        outputs -- see model._encode)."""
         Hd = x.shape[1]
         R = n * L
         rowmap = pair[0] if pair is not None else None
@@ -504,29 +511,35 @@ class BertLayerFn(torch.autograd.Function):
         cx = torch.empty((R, Hd), dtype=bf16, device=x.device)
         att.fwd(qkv, cx, lse)
         ao = layer.attention.output
+        resln_in = x32 if isinstance(x32, tuple) else None          # (pre, mean, rstd, gamma, beta) of the producing LayerNorm
         pre1 = K.gemm(0, cx, W16(ao.dense.weight), R, Hd, Hd, bias=ao.dense.bias.data, dropout_p=p_hidden, seed=s1,
-                      residual=x32 if x32 is not None else x, res_rowmap=rowmap, out_dtype=sdt)
-        x1_32 = torch.empty((R, Hd), dtype=f32, device=x.device) if STREAM32 else None
+                      residual=(resln_in[0] if resln_in is not None else (x32 if x32 is not None else x)), res_rowmap=rowmap,
+                      res_ln=(resln_in[1:] if resln_in is not None else None), out_dtype=sdt)
+        x1_32 = torch.empty((R, Hd), dtype=f32, device=x.device) if (STREAM32 and not RESLN) else None
         x1, mean1, rstd1 = K.layernorm_fwd(pre1, R, Hd, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, ao.LayerNorm.eps,
-                                           want_stats=keep, out32=x1_32)
+                                           want_stats=keep or RESLN, out32=x1_32)
         inter, outp = layer.intermediate, layer.output
         F = inter.dense.weight.shape[0]
         h_pre = torch.empty((R, F), dtype=_GQ_DT, device=x.device) if keep else None
         h = K.gemm(0, x1, W16(inter.dense.weight), R, F, Hd, bias=inter.dense.bias.data, act=1, preact=h_pre, preact_is_grad=_GQ)
         pre2 = K.gemm(0, h, W16(outp.dense.weight), R, Hd, F, bias=outp.dense.bias.data, dropout_p=p_hidden, seed=s2,
-                      residual=x1_32 if STREAM32 else x1, out_dtype=sdt)
-        y32 = torch.empty((R, Hd), dtype=f32, device=x.device) if (STREAM32 and want32) else None
+                      residual=(pre1 if RESLN else (x1_32 if STREAM32 else x1)),
+                      res_ln=((mean1, rstd1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data) if RESLN else None), out_dtype=sdt)
+        y32 = torch.empty((R, Hd), dtype=f32, device=x.device) if (STREAM32 and want32 and not RESLN) else None
         y, mean2, rstd2 = K.layernorm_fwd(pre2, R, Hd, outp.LayerNorm.weight.data, outp.LayerNorm.bias.data, outp.LayerNorm.eps,
-                                          want_stats=keep, out32=y32)
+                                          want_stats=keep or (RESLN and want32), out32=y32)
         if keep:
             ctx.layer, ctx.att, ctx.seeds, ctx.p = layer, att, (s1, s2), p_hidden
             ctx.pair = pair
             ctx.save_for_backward(x, qkv, cx, lse, pre1, mean1, rstd1, x1, h_pre, h, pre2, mean2, rstd2)
+        if RESLN and want32:
+            ctx.mark_non_differentiable(pre2, mean2, rstd2)
+            return y, pre2, mean2, rstd2
         ctx.mark_non_differentiable(*([y32] if y32 is not None else []))
         return y, y32
 
     @staticmethod
-    def backward(ctx, dy, _dy32=None):
+    def backward(ctx, dy, *_unused):
         layer, att, (s1, s2), p = ctx.layer, ctx.att, ctx.seeds, ctx.p
         x, qkv, cx, lse, pre1, mean1, rstd1, x1, h_pre, h, pre2, mean2, rstd2 = ctx.saved_tensors
         R, Hd = cx.shape

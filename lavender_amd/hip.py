@@ -43,9 +43,10 @@ def _ld(t):
 def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, preact=None, gelu_in=None, dropout_p=0.0,
          seed=0, row_scale=None, rows_per_group=1, residual=None, colsum=None, alpha=1.0, accumulate=False,
          k_keep=None, k_rows_per_group=1, splits=1, ldc=None, rowsum_a=None, preact_is_grad=False, gelu_in_is_grad=False,
-         a_rowmap=None, res_rowmap=None):
+         a_rowmap=None, res_rowmap=None, res_ln=None):
     """layout 0: A[M,K] B[N,K]; 1: A[M,K] B[K,N]; 2: A[K,M] B[K,N].  Returns the (M, N) output view.
-    a_rowmap / res_rowmap (int32 [M]): logical row m of A / of the residual is physical row map[m] (pair expansion, layout 0)."""
+    a_rowmap / res_rowmap (int32 [M]): logical row m of A / of the residual is physical row map[m] (pair expansion, layout 0).
+    res_ln = (mean, rstd, gamma, beta): `residual` (fp32) is a PRE-LayerNorm tensor, the epilogue adds LayerNorm(residual)."""
     dev = A.device
     if out is None:
         ldc = ldc or ((N + 7) // 8 * 8)
@@ -76,6 +77,9 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
     e.gelu_in_is_grad = int(gelu_in_is_grad)
     e.a_rowmap = _p(a_rowmap)
     e.res_rowmap = _p(res_rowmap)
+    if res_ln is not None:
+        assert residual is not None and residual.dtype == torch.float32 and out.dtype == torch.float32
+        e.res_ln_mean, e.res_ln_rstd, e.res_ln_gamma, e.res_ln_beta = (_p(t) for t in res_ln)
     L.check(L.lib.lav_gemm_bf16(_s(), layout, M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc, C.byref(e), splits),
             "lav_gemm_bf16")
     return out[:, :N] if out.shape[-1] != N else out

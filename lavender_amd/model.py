@@ -209,7 +209,12 @@ class LAVENDER_Base(nn.Module):
         pa = self.config.attention_probs_dropout_prob if self.training else 0.0
         x32, last = None, len(self.trsfr.layer) - 1
         for i, lyr in enumerate(self.trsfr.layer):
-            x, x32 = E.BertLayerFn.apply(arena.anchor, x, x32, lyr, km, n, L, ph, pa, i < last, int(causal_from), pair if i == 0 else None)
+            out = E.BertLayerFn.apply(arena.anchor, x, x32, lyr, km, n, L, ph, pa, i < last, int(causal_from), pair if i == 0 else None)
+            if len(out) == 4:                                 # engine.RESLN: the next residual add normalises this layer's pre-LN rows itself
+                ln = lyr.output.LayerNorm
+                x, x32 = out[0], (out[1], out[2], out[3], ln.weight.data, ln.bias.data)
+            else:
+                x, x32 = out
         return x.view(n, L, Hd)
 
     def _pair_source(self, feat_img, feat_txt, vi, ti):

@@ -358,6 +358,60 @@ def test_weight_gradient_side_stream_is_race_free():
         E._DW_SIDE = keep
 
 
+def test_residual_layernorm_in_the_gemm_epilogue_is_bit_identical():
+    """engine.RESLN: the fp32 copy of a LayerNorm output is not written; the next residual add normalises the saved pre-LN rows in
+    its GEMM epilogue (lav_gemm_epilogue.res_ln_*).  Same arithmetic as lav_layernorm_fwd -> same logits and weight gradients, bit
+    for bit, in train mode (dropout and drop-path on, identical seeds)."""
+    from tests.helpers import Tok, make_args
+    import lavender_amd as LA
+    import lavender_amd.engine as E
+    from lavender_amd import hip as K
+    from lavender_amd.dist import set_seed
+    assert E.STREAM32
+    B = 4
+    set_seed(88)
+    args = make_args("micro", "micro", B)
+    m = LA.LAVENDER_Pretrain_MLM(args, Tok()).cuda()
+    ar = m.arena()
+    ag = LA.Agent_Pretrain_MLM(args, m)
+    b = make_batch(B, vocab=BERT_CFGS["micro"]["vocab"])
+    torch.manual_seed(5)
+    b.update(ag.masking(b["txt"], b["mask"]))
+    batch = ag.prepare_batch(b)
+    wnames = [n for n, p in m.named_parameters() if p.dim() == 2 and n.endswith("weight") and "embeddings" not in n]
+
+    def run(resln, side):
+        E.RESLN, E._DW_SIDE = resln, side
+        K.reseed(4321)
+        np.random.seed(3)
+        m.train()
+        ar.zero_grad()
+        out = m(batch)
+        ls = (ag.loss_func(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten(), batch["_n_mtm"]) +
+              ag.loss_func(out["out_vtm"].flatten(0, 1), out["ans_vtm"].flatten(), B * 4))
+        logits = out["out_mtm"].detach().clone()
+        ls.backward()
+        torch.cuda.synchronize()
+        return logits, {n: ar.params[n].grad.clone() for n in wnames}
+
+    keep = (E.RESLN, E._DW_SIDE)
+    try:
+        l0, g0 = run(False, False)
+        l1, g1 = run(True, False)
+        assert torch.equal(l0, l1)
+        bad = [n for n in wnames if not torch.equal(g0[n], g1[n])]
+        assert not bad, bad[:5]
+        m.eval()
+        with torch.no_grad():
+            E.RESLN = False
+            e0 = m(batch)["out_mtm"].clone()
+            E.RESLN = True
+            e1 = m(batch)["out_mtm"].clone()
+        assert torch.equal(e0, e1)
+    finally:
+        E.RESLN, E._DW_SIDE = keep
+
+
 def test_load_ckpt_refreshes_the_working_copies(tmp_path):
     """load_ckpt on a model that already lives in a ParamArena: fp32 master, bf16 copy and the transposed copy all follow
     (forward AND backward then match the model the checkpoint came from)."""
