@@ -106,7 +106,9 @@ __device__ __forceinline__ TokInfo win_token(const AttnArgs& a, int win, int i) 
 template <int HD>
 __device__ __forceinline__ int krow_off(int row, int slot) {
     if (HD == 32) return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
-    return row * 128 + ((slot ^ (row & 7)) << 4);             // 8 consecutive rows -> 8 distinct 16-byte bank groups (a 128-byte row is a full bank sweep)
+    // LDS has 64 banks (256 B per cycle): two consecutive 128-byte rows sweep the banks once, so the slot XOR advances every SECOND row --
+    // 16 consecutive rows then hit 16 distinct 16-byte bank groups.  (XOR by row & 7 was tried in round 3: SQ_LDS_BANK_CONFLICT doubled.)
+    return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
