@@ -53,7 +53,7 @@ __device__ __forceinline__ void seq_dma_image(unsigned lds_img, const bf16_t* ba
     for (int t = wave; t < npiece; t += 4) {
         const int row = min(t * 8 + (lane >> 3), L - 1);
         const int prow = t * 8 + (lane >> 3);
-        const int lslot = (lane & 7) ^ ((prow >> 1) & 7);
+        const int lslot = (lane & 7) ^ swz64(prow);
         sdma16(lds_img + t * 1024, base, (unsigned)((row * ld + lslot * 8) * 2));
     }
 }
@@ -463,7 +463,7 @@ __device__ __forceinline__ void seql_dma_chunk(unsigned lds_img, const bf16_t* b
         const int t = wave * 4 + i;
         const int prow = t * 8 + (lane >> 3);
         const int row = min(row0 + prow, L - 1);
-        const int lslot = (lane & 7) ^ ((prow >> 1) & 7);
+        const int lslot = (lane & 7) ^ swz64(prow);
         sdma16(lds_img + t * 1024, base, (unsigned)((row * ld + lslot * 8) * 2));
     }
 }

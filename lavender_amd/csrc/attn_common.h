@@ -103,12 +103,17 @@ __device__ __forceinline__ TokInfo win_token(const AttnArgs& a, int win, int i) 
 
 // K-type LDS tile: rows of HD bf16 (d contiguous), 16-byte slots XOR-swizzled so that the 32x32 A-operand
 // read (32 rows x one slot) is bank-conflict-free.
+// slot XOR of a 128-byte-row (head_dim 64) image: a permutation of (row >> 1) & 7 -- the eight row pairs of a 16-row ds_read_b128 group
+// still land on eight distinct bank groups -- chosen so that rows r and r + 2 (same bank half) differ by 4, not 1: the two adjacent
+// slots a ds_read_b64_tr_b16 group takes from rows r .. r + 3 then never coincide.
+__device__ __forceinline__ int swz64(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
 template <int HD>
 __device__ __forceinline__ int krow_off(int row, int slot) {
     if (HD == 32) return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
     // LDS has 64 banks (256 B per cycle): two consecutive 128-byte rows sweep the banks once, so the slot XOR advances every SECOND row --
     // 16 consecutive rows then hit 16 distinct 16-byte bank groups.  (XOR by row & 7 was tried in round 3: SQ_LDS_BANK_CONFLICT doubled.)
-    return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+    return row * 128 + ((slot ^ swz64(row)) << 4);
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
