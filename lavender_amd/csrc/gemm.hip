@@ -220,7 +220,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
     const bool full = GEN ? ncols == 8 : true;
     const bool inside = GEN ? ncols == 8 : ncols > 0;
     constexpr int NIT = ROWS / RPP;
-    constexpr int GRP = 4;                                 // rows handled together: their gelu_in / residual loads are
+    constexpr int GRP = NIT < 4 ? NIT : 4;                 // rows handled together: their gelu_in / residual loads are
     static_assert(NIT % GRP == 0, "epilogue row grouping");  // issued back-to-back so HBM latency is paid once per group
 #pragma unroll 1
     for (int j0 = 0; j0 < NIT; j0 += GRP) {
@@ -793,8 +793,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
 // RF = 16-row fragments per wave: 8 -> 256-row tiles; 6 -> 192-row tiles (K-contiguous layouts with a specialised epilogue only):
 // a 45120 x 768 output is 531 tiles of 256 x 256 = 2.07 rounds on 256 CUs (a third of the last round's CUs idle for a whole
 // tile), but 705 tiles of 192 x 256 = 2.75 rounds of 3/4-size tiles.
-template <bool AKC, bool BKC, unsigned F, int NW, int RF = 8, int BNT = 256>
+template <bool AKC, bool BKC, unsigned F, int NW, int RF = 8, int BNT = 256, int LW = 0>
 __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
+    static_assert(LW == 0 || (AKC && BKC && NW == 8 && F != EF_ALL && F != EF_TNFLUSH), "loader waves: both operands K-contiguous, specialised epilogue");
     constexpr int BMT = 2 * RF * 16;                      // tile rows
     constexpr int IPA = BMT / 8 / NW;                     // direct-to-LDS wave-instructions per A tile per wave (K-contiguous A)
     static_assert(RF == 8 || (AKC && F != EF_ALL && F != EF_TNFLUSH), "192-row tiles: K-contiguous A, specialised epilogue");
@@ -833,6 +834,47 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nk = (kend - kbeg) / BKT;
 
+    if constexpr (LW > 0) {
+        // Loader waves (wave >= NW): they issue EVERY direct-to-LDS instruction of the k-loop -- a global_load_lds issue holds its wave for
+        // 60-185 cycles, time the eight compute waves then spend on fragment reads and MFMAs instead -- wait for their own loads and
+        // meet the compute waves at the k-tile barrier; they leave before the (barrier-free) epilogue.
+        if (wave >= NW) {
+            const int lw = wave - NW;
+            constexpr int PA = BMT / 8 / LW, PB = BNT / 8 / LW;
+            const bf16_t* ar[PA];
+            const bf16_t* br[PB];
+            const int sw = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                int r = min(m0 + (lw * PA + i) * 8 + (lane >> 3), g.M - 1);
+                if (g.e.a_rowmap) r = g.e.a_rowmap[r];
+                ar[i] = g.A + (long)r * g.lda + sw;
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) br[i] = g.B + (long)min(n0 + (lw * PB + i) * 8 + (lane >> 3), g.N - 1) * g.ldb + sw;
+            auto load_tile = [&](int kt) {
+                char* st = smem + (kt & 1) * STAGE;
+                const int k0 = kbeg + kt * BKT;
+#pragma unroll
+                for (int i = 0; i < PA; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ar[i] + k0),
+                                                     (__attribute__((address_space(3))) void*)(st + (lw * PA + i) * 1024), 16, 0, 0);
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(br[i] + k0),
+                                                     (__attribute__((address_space(3))) void*)(st + BOFF + (lw * PB + i) * 1024), 16, 0, 0);
+            };
+            if (nk > 0) load_tile(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + 1 < nk) load_tile(kt + 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            return;
+        }
+    }
     f32x4 acc[RF][NJ];
 #pragma unroll
     for (int i = 0; i < RF; ++i)
@@ -872,14 +914,14 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
         if (BKC) big_glds<true, IPB>(st + BOFF, g.B, g.ldb, n0, g.N, k0, wave, lane);
         else huge_glds_strided<IPW>(st + BOFF, g.B, g.ldb, n0, g.N, k0, wave, lane);
     };
-    if (nk > 0) issue(0);
+    if (LW == 0 && nk > 0) issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     for (int kt = 0; kt < ((g.dbg & 2) ? 0 : nk); ++kt) {
         const char* la = smem + (kt & 1) * STAGE;
         const char* lb = la + BOFF;
-        if (kt + 1 < nk) issue(kt + 1);
+        if (LW == 0 && kt + 1 < nk) issue(kt + 1);
         int kmode = 1;
         if (!AKC && g.e.k_keep) {
             int kb; bool keep0, keep1;
@@ -929,7 +971,7 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
         // launches within +-3 %), with 64-byte pieces equal (77.9): partial-line writes and residual reads are what the step, run
         // next to the weight-gradient stream, cannot afford.  The LDS-staged full-line form stays.
         constexpr int WS = 68;                            // private row stride (floats)
-        constexpr int CF = RF == 8 ? 4 : 2;               // 16-row fragments per staged chunk: 64-row halves (256-row tile) or 32-row thirds
+        constexpr int CF = RF == 8 ? 4 : (RF % 2 == 0 ? 2 : 1); // 16-row fragments per staged chunk: 64-row halves (256-row tile), 32-row thirds, or single fragments
         float* clw = (float*)smem + wave * (64 * WS);
 #pragma unroll
         for (int h = 0; h < RF / CF; ++h) {               // unrolled: acc[] must be indexed with compile-time constants
@@ -975,6 +1017,14 @@ template <bool AKC, bool BKC, unsigned F = EF_ALL>
 __global__ __launch_bounds__(512) void gemm_huge_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 8>(g); }
 template <bool AKC, bool BKC, unsigned F>
 __global__ __launch_bounds__(512) void gemm_h192_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 8, 6>(g); }
+// 192 x 256 tiles, eight compute waves + two LOADER waves (640 threads; the 155 registers of the 192-row body fit three waves per SIMD).
+// Bit-identical to gemm_h192_kernel; isolated -2 ... -12 % on the shapes the 192-row tile is chosen for (45120 x 768 x {768, 2304, 3072}: the
+// longer K, the more), -0.2 ... -0.3 ms on the cfg2 step (at the edge of the run-to-run noise).  Forced on every 256-column shape (LAV_GEMM_H192L=2, tools/h192l_probe.py) it loses 5-50 %
+// to the 256-row tile elsewhere.  The 256-row tile with loader waves (A fragments read four at a time to fit 168 registers: 164, no spills)
+// won 2-9 % isolated on the wide fusion outputs and LOST 0.8 ms in the step (three resident waves per SIMD next to the weight-gradient
+// stream), so it is not kept.
+template <bool AKC, bool BKC, unsigned F>
+__global__ __launch_bounds__(640) void gemm_h192l_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 8, 6, 256, 2>(g); }
 // 192 x 128 tiles on FOUR waves (2 x 2 of 96 x 64, the h192 wave tile) with 2 x 40 KB of stages: TWO workgroups fit a CU (LDS 2 x 80 KB,
 // 162 VGPRs, 2 waves per SIMD), so one workgroup's epilogue (HBM-bound, matrix pipe idle) runs under the other's k-loop.  Round-3
 // experiment, NOT selected by default (LAV_GEMM_Q=1 forces it, 9 = long-K narrow outputs only; tools/q_probe.py): bit-identical results;
@@ -1450,6 +1500,7 @@ static bool lav_gemm_pp_tn = getenv("LAV_GEMM_PP_TN") ? atoi(getenv("LAV_GEMM_PP
 // 45120 x 3072 x 768 GEMMs and on 8192^3, nothing on narrower outputs).  LAV_GEMM_GROUP_N=0 restores n-fastest, other values force G.
 static int lav_gemm_group_n = getenv("LAV_GEMM_GROUP_N") ? atoi(getenv("LAV_GEMM_GROUP_N")) : -1;
 static int lav_gemm_h192 = getenv("LAV_GEMM_H192") ? atoi(getenv("LAV_GEMM_H192")) : 1;          // 192-row tiles for outputs that under-fill the last round of 256-row tiles
+static int lav_gemm_h192l = getenv("LAV_GEMM_H192L") ? atoi(getenv("LAV_GEMM_H192L")) : 1;                         // 192-row tiles: two loader waves issue the operand DMA (0 = off, 2 = probe: on every 256-column shape)
 static int lav_gemm_q = getenv("LAV_GEMM_Q") ? atoi(getenv("LAV_GEMM_Q")) : 0;                                     // 192x128 four-wave tiles, two workgroups per CU
 static int lav_gemm_dbg = getenv("LAV_GEMM_DBG") ? atoi(getenv("LAV_GEMM_DBG")) : 0;                               // probe hook: GemmArgs.dbg of the 256x256 kernel
 static int lav_gemm_pp_dbg = 0;                            // ablation builds of the ping-pong kernel (probe only, wrong results): 1 no refills, 2 no fragment reads, 4 no MFMAs
@@ -1462,6 +1513,7 @@ extern "C" int lav_gemm_select(int which, int value) {    // probe hook (within-
     if (which == 6) { old = lav_gemm_group_n; lav_gemm_group_n = value; }
     if (which == 7) { old = lav_gemm_h192; lav_gemm_h192 = value; }
     if (which == 8) { old = lav_gemm_q; lav_gemm_q = value; }
+    if (which == 9) { old = lav_gemm_h192l; lav_gemm_h192l = value; }
     return old;
 }
 
@@ -1522,8 +1574,8 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
                        S_BDR = EF_BIAS | EF_DROP | EF_RSCALE | EF_RES, S_BDRO = S_BDR | EF_O32;
     const unsigned fsel = !(fm & ~S_B) ? S_B : !(fm & ~S_BG) ? S_BG : !(fm & ~S_GC) ? S_GC : !(fm & ~S_BDR) ? S_BDR :
                           ((fm & EF_O32) && !(fm & ~S_BDRO)) ? S_BDRO : EF_ALL;
-    constexpr int lav_threads_gemm_huge_kernel = 512, lav_threads_gemm_big_kernel = 512, lav_threads_gemm_h192_kernel = 512, lav_threads_gemm_q_kernel = 256;
-    (void)lav_threads_gemm_huge_kernel; (void)lav_threads_gemm_big_kernel; (void)lav_threads_gemm_h192_kernel; (void)lav_threads_gemm_q_kernel;
+    constexpr int lav_threads_gemm_huge_kernel = 512, lav_threads_gemm_big_kernel = 512, lav_threads_gemm_h192_kernel = 512, lav_threads_gemm_q_kernel = 256, lav_threads_gemm_h192l_kernel = 640;
+    (void)lav_threads_gemm_huge_kernel; (void)lav_threads_gemm_big_kernel; (void)lav_threads_gemm_h192_kernel; (void)lav_threads_gemm_q_kernel; (void)lav_threads_gemm_h192l_kernel;
 #define LAV_LAUNCH_ONE(KERN, AKC_, BKC_, F_, GRID, LDS)                                                                   \
     do {                                                                                                                  \
         static bool attr_done = false;                                                                                    \
@@ -1587,6 +1639,18 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
         return lav_check_launch("lav_gemm_bf16");
     }
+    if (big && lav_gemm_h192l == 2 && layout == 0 && fsel != EF_ALL && (N % 256) == 0 && !g.e.a_rowmap) {     // probe: loader-wave tiles everywhere
+        g.k_per_split = K;
+        g.dbg = lav_gemm_dbg;
+        const int tn_ = N / 256;
+        g.group_n = lav_gemm_group_n >= 0 ? lav_gemm_group_n : (tn_ >= 8 && tn_ % 4 == 0 ? 4 : 0);
+        dim3 lgrid((unsigned)t_h192);
+#define LAV_HL(F_) LAV_LAUNCH_ONE(gemm_h192l_kernel, true, true, F_, lgrid, HUGE_LDS);
+        if (fsel == S_B) LAV_HL(S_B) else if (fsel == S_BG) LAV_HL(S_BG) else if (fsel == S_GC) LAV_HL(S_GC)
+        else if (fsel == S_BDR) LAV_HL(S_BDR) else LAV_HL(S_BDRO)
+#undef LAV_HL
+        return lav_check_launch("lav_gemm_bf16");
+    }
     if (big && lav_gemm_q && layout == 0 && fsel != EF_ALL && (N % 128) == 0 && (lav_gemm_q != 9 || (N <= 768 && K >= 2048 && M >= 16384))) {
         g.k_per_split = K;
         g.dbg = lav_gemm_dbg;
@@ -1603,7 +1667,7 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         g.k_per_split = K;
         g.dbg = lav_gemm_dbg; g.group_n = 0;
         dim3 hgrid((unsigned)t_h192);
-#define LAV_H192(F_) { if (layout == 0) LAV_LAUNCH_ONE(gemm_h192_kernel, true, true, F_, hgrid, HUGE_LDS); else LAV_LAUNCH_ONE(gemm_h192_kernel, true, false, F_, hgrid, HUGE_LDS); }
+#define LAV_H192(F_) { if (layout == 0 && lav_gemm_h192l) LAV_LAUNCH_ONE(gemm_h192l_kernel, true, true, F_, hgrid, HUGE_LDS); else if (layout == 0) LAV_LAUNCH_ONE(gemm_h192_kernel, true, true, F_, hgrid, HUGE_LDS); else LAV_LAUNCH_ONE(gemm_h192_kernel, true, false, F_, hgrid, HUGE_LDS); }
         if (fsel == S_B) LAV_H192(S_B) else if (fsel == S_BG) LAV_H192(S_BG) else if (fsel == S_GC) LAV_H192(S_GC)
         else if (fsel == S_BDR) LAV_H192(S_BDR) else LAV_H192(S_BDRO)
 #undef LAV_H192
