@@ -39,7 +39,7 @@ if len(sys.argv) > 3:
 if len(sys.argv) > 5:
     import json
     steps = int(sys.argv[5])
-    fam = [k for k in f if re.search(r"gemm_(huge_|h192_|big_|q_)?kernel<true, true", k)]
+    fam = [k for k in f if re.search(r"gemm_(huge_|h192_|h192l_|big_|q_)?kernel<true, true", k)]
     n = sum(f[k][0] for k in fam)
     fb = sum(f[k][1] for k in fam) * 2 * 1024 / n
     wb = sum(w.get(k, (0, 0, 0))[1] for k in fam) * 1024 / n
