@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+TRAFFIC_FILE = "r04_pmc_hbm_traffic" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")) else "r03_pmc_hbm_traffic"   # newest committed PMC traffic table
 
 
 def flops_per_sample(E=128, depths=(2, 2, 18, 2), T=5, S=224, X=32, layers=12, hid=768, vocab=30522, n_seq=5, win=(8, 7, 7)):
@@ -312,6 +313,35 @@ def main():
         dt = float(t.item())
     loss_vals = {k: float(v) for k, v in last.items()}
 
+    # ---- the reference's own loop semantics (go_dl, main_pretrain_mlm.py:202-232 + step :145-176), timed beside the contract value: per
+    # step a HOST batch (pinned, as a DataLoader with pin_memory hands it over), masking() on the host, prepare_batch (H2D of frames,
+    # ids, labels) and .item() on both losses -- i.e. one device round trip per step and no enqueue run-ahead
+    ref_loop_ms = None
+    if not retrieval and feed is None and use_cuda:
+        host_batches = []
+        for i in range(nb):
+            hb = synth_batch(B, T, S, X, rank * 7 + i, "cpu")
+            host_batches.append({k: v.pin_memory() for k, v in hb.items()})
+        n_ref = max(5, min(20, a.steps))
+
+        def ref_step(i):
+            hb = host_batches[i % nb]
+            b = dict(img=hb["img"], txt=hb["txt"].clone(), mask=hb["mask"])
+            b.update(agent.masking(b["txt"], b["mask"]))
+            return agent.step(agent.prepare_batch(b), True)         # sync=True: ls_mtm.item(), ls_vtm.item()
+        for i in range(2):
+            ref_step(i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(n_ref):
+            ref_step(i)
+        barrier()
+        ref_loop_ms = (time.perf_counter() - t1) * 1e3 / n_ref
+        if world > 1:
+            t = torch.tensor([ref_loop_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ref_loop_ms = float(t.item())
+
     # ---- dominant-kernel roofline: every K-contiguous (layout 0) GEMM launch of one more step, HIP events on its stream ----
     # every rank runs the sampling step (it contains the gradient all-reduce); only rank 0 instruments and reports
     roof = None
@@ -355,7 +385,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE + ".json")) as fh:
                 pm = json.load(fh)
             if a.workload == "cfg2" and B == 32 and a.layers == 12 and a.size == "base":
                 traffic = pm["hbm_bytes_per_launch"]
@@ -366,10 +396,10 @@ def main():
         for lay_i, fl_i, e0_i, e1_i, _nb_i in rec_iso:
             if lay_i == 0:
                 iso[0] += 1; iso[1] += fl_i; iso[2] += e0_i.elapsed_time(e1_i) * 1e-3
-        roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T and input-gradient dy.(W^T)^T GEMMs: gemm_huge / gemm_h192l / gemm_big / gemm_kernel<NT>)",
+        roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T and input-gradient dy.(W^T)^T GEMMs: gemm_p256 / gemm_p192l persistent tile walkers, gemm_huge / gemm_big / gemm_kernel<NT>)",
                 "achieved": round(fl / tm / 1e12, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tm / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_pmc_hbm_traffic.md)",
+                "traffic_unit": f"HBM bytes per launch, STATIC: read from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE, profiles/{TRAFFIC_FILE}.md), not collected in this run",
                 "algorithmic_bytes_per_launch": round(nb / n),
                 "launches_per_step": n, "avg_launch_us": round(tm / n * 1e6, 2), "avg_launch_gflop": round(fl / n / 1e9, 3),
                 "note": "achieved / avg_launch_us are measured in the shipped configuration, where weight-gradient GEMMs of a second "
@@ -396,7 +426,9 @@ def main():
             what = "SIDE CASE loss-aware head (labelled positions only, not the reference's full-logit outputs) -- " + what
         out = {"metric": "video-text samples/sec (node) pretrain step, Swin-B 5x224^2 + 32-tok", "value": round(value, 2),
                "unit": "samples/s", "n_gpus": world, "world_size_observed": (dist.get_world_size() if world > 1 else 1),
-               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "ms_per_step_median_hip_events": round(ms_median, 2), "ms_per_step_p99_hip_events": round(ms_p99, 2), "host_enqueue_ms_per_step": round(host_ms, 2),
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
+               "ms_per_step_reference_loop": (round(ref_loop_ms, 2) if ref_loop_ms is not None else None),
+               "ms_per_step_median_hip_events": round(ms_median, 2), "ms_per_step_p99_hip_events": round(ms_p99, 2), "host_enqueue_ms_per_step": round(host_ms, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic" if a.input == "resident" else "SIDE CASE input pipeline in the timed region: fixture JPEG frames (320x240, "
                        "replicated rows) read from a TSV, decoded / resized / cropped on the GPU, host masking, per step",
@@ -405,6 +437,9 @@ def main():
                                       f"fwd+bwd+clip+AdamW, dropout 0.1 / drop-path 0.2 on; "
                                       + ("inputs resident in HBM, labels prebuilt: host masking() + H2D copy are outside the timed region"
                                          if a.input == "resident" else "input pipeline + host masking() inside the timed region"),
+                          "loop": "value / ms_per_step: device-scalar losses (agent.step(sync=False): no .item() per step), pre-masked batches resident in HBM; "
+                                  "ms_per_step_reference_loop: the reference's go_dl semantics (main_pretrain_mlm.py:202-232, :167-169) -- pinned host batch, "
+                                  "host masking(), prepare_batch H2D of frames + ids + labels, .item() on both losses every step",
                           "per_gpu_batch": B, "global_batch": B * world, "frames": T, "size_img": S, "size_txt": X,
                           "parallelism": f"dp{world}", "params_M": round(nparam / 1e6, 2),
                           "algorithmic_tflop_per_step_per_gpu": round(fstep * B / 1e12, 2),

@@ -136,9 +136,10 @@ class Agent_Base:
             json.dump(dict(self.args), open(f'{self.args.path_output}/args.json', 'w'), indent=2)
             self.save_model(0)
 
-    def _save_state(self, filename):
-        """rank-0 torch.save of the CPU state_dict as `filename` under args.path_output (every rank must call this: with
-        ZeRO-1 all ranks take part in re-assembling the fp32 masters)."""
+    def _save_state(self, filename, write_log=True):
+        """rank-0 torch.save of the CPU state_dict as `filename` under args.path_output.  EVERY RANK MUST CALL THIS (and therefore
+        save_model): with ZeRO-1 (args.deepspeed) gather_master() below is a collective that re-assembles the fp32 masters, so a
+        caller that guards save_model with is_main_process() would hang the other ranks; only the file write is rank-0-only."""
         if self.dp is not None:
             self.dp.gather_master()
         if is_main_process():
@@ -146,11 +147,11 @@ class Agent_Base:
             os.makedirs(output_dir, exist_ok=True)
             sd = {k: v.cpu() if isinstance(v, torch.Tensor) else v for k, v in self._unwrapped().state_dict().items()}
             torch.save(sd, f"{output_dir}/{filename}")
-            if self.log is not None:
+            if write_log and self.log is not None:
                 json.dump(self.log, open(f"{output_dir}/log.json", 'w'), indent=2)
 
     def save_model(self, ep):
-        """agent.py:164-180: ckpt_violet_{task}_{ep}.pt."""
+        """agent.py:164-180: ckpt_violet_{task}_{ep}.pt (+ log.json).  Call on every rank (see _save_state)."""
         self._save_state(f"ckpt_violet_{self.args.task}_{ep}.pt")
 
     def log_memory(self, ep=-1, step=-1):

@@ -153,8 +153,15 @@ enum : unsigned { EF_BIAS = 1, EF_ACT = 2, EF_GIN = 4, EF_DROP = 8, EF_RSCALE = 
 
 // CH = 16-byte chunks per staged row (16: a 128-column block-wide tile; 8: a 64-column tile private to ONE wave -- then
 // NTHR == 64, `cl` is that wave's LDS slice with row stride CSTR and nothing here synchronises the block).
+// Per-(wave, tile) epilogue state that does not depend on the row chunk: the lane's 8 columns of bias / LayerNorm affine, and the running
+// column sums.  The wave-private epilogues walk a tile in 2-4 row chunks; loading these once per tile (epi_begin) instead of once per
+// chunk takes a dependent global load (and, for the column sums, an LDS reduction + 64 atomics) out of every chunk.
+struct EpiState { float bias[8], lng[8], lnb[8], csum[8]; };
+
 template <int ROWS, int NTHR, unsigned F = EF_ALL, int CH = 16, int CSTR = CSTRIDE>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int m0, int n0, int split = 0) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int m0, int n0, int split, EpiState& st, const int phase) {
+    // phase (a compile-time constant at every call site): bit 0 = (re)load the per-tile state into `st` before the rows, bit 1 = flush
+    // the column sums after the rows (first chunk: 1, middle chunks: 0, last chunk: 2, self-contained call: 3)
     constexpr bool WAVE = CH != 16;
     constexpr int RPP = NTHR / CH;                          // rows per pass
     const lav_gemm_epilogue& e = g.e;
@@ -199,21 +206,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
     const int etid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
     const int cc = etid % CH;
     const int gcol = n0 + cc * 8;
-    float csum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float (&csum)[8] = st.csum;
+    float (&bias)[8] = st.bias;
+    float (&lng)[8] = st.lng;
+    float (&lnb)[8] = st.lnb;
     const int ncols = min(8, g.N - gcol);              // <=0: chunk outside
-    if (has_bias && ncols > 0) {
-#pragma unroll
-        for (int x = 0; x < 8; ++x)
-            if (x < ncols) bias[x] = e.bias[gcol + x];
-    }
-    // LayerNorm of the residual rows (res_ln_*): this thread's 8 columns of gamma / beta, once
-    float lng[8] = {1, 1, 1, 1, 1, 1, 1, 1}, lnb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool has_resln = (GEN || (F & EF_O32)) && (F & EF_RES) && e.residual && e.residual_f32 && e.res_ln_mean;
-    if (has_resln && ncols > 0) {
+    if (phase & 1) {
 #pragma unroll
-        for (int x = 0; x < 8; ++x)
-            if (x < ncols) { lng[x] = e.res_ln_gamma[gcol + x]; lnb[x] = e.res_ln_beta[gcol + x]; }
+        for (int x = 0; x < 8; ++x) { csum[x] = 0.f; bias[x] = 0.f; lng[x] = 1.f; lnb[x] = 0.f; }
+        if (has_bias && ncols > 0) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+                if (x < ncols) bias[x] = e.bias[gcol + x];
+        }
+        // LayerNorm of the residual rows (res_ln_*): this thread's 8 columns of gamma / beta, once
+        if (has_resln && ncols > 0) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+                if (x < ncols) { lng[x] = e.res_ln_gamma[gcol + x]; lnb[x] = e.res_ln_beta[gcol + x]; }
+        }
     }
     // specialised variants are only dispatched when N % 8 == 0: a chunk is whole or outside the matrix, so past the
     // "outside" test every access is a full 16-byte one (compile-time) -- the preloads below run BEFORE that test
@@ -382,7 +394,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         }
       }
     }
-    if (has_colsum) {
+    if (has_colsum && (phase & 2)) {
         constexpr int W = CH * 8;                           // staged tile width in columns
         if (WAVE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); else __syncthreads();
         float* red = cl;                                  // [RPP][W]
@@ -396,6 +408,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             atomicAdd(e.colsum + n0 + etid, s);
         }
     }
+}
+
+template <int ROWS, int NTHR, unsigned F = EF_ALL, int CH = 16, int CSTR = CSTRIDE>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int m0, int n0, int split = 0) {
+    EpiState st;
+    gemm_epilogue<ROWS, NTHR, F, CH, CSTR>(g, cl, m0, n0, split, st, 3);
 }
 
 // KG = number of 4-wave groups per block.  KG == 2 (weight gradients): the two groups walk alternate k-tiles of
@@ -973,6 +991,7 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
         constexpr int WS = 68;                            // private row stride (floats)
         constexpr int CF = RF == 8 ? 4 : (RF % 2 == 0 ? 2 : 1); // 16-row fragments per staged chunk: 64-row halves (256-row tile), 32-row thirds, or single fragments
         float* clw = (float*)smem + wave * (64 * WS);
+        EpiState es;                                       // bias / LayerNorm affine / column sums of this wave's 64 columns: once per tile
 #pragma unroll
         for (int h = 0; h < RF / CF; ++h) {               // unrolled: acc[] must be indexed with compile-time constants
             if (!(g.dbg & 4)) {
@@ -986,7 +1005,8 @@ __device__ __forceinline__ void gemm_huge_body(const GemmArgs& g) {
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the slice is only read by this wave
             __builtin_amdgcn_wave_barrier();
-            gemm_epilogue<CF * 16, 64, F, 8, WS>(g, clw, m0 + wm * (RF * 16) + h * (CF * 16), n0 + wn * 64, split);
+            gemm_epilogue<CF * 16, 64, F, 8, WS>(g, clw, m0 + wm * (RF * 16) + h * (CF * 16), n0 + wn * 64, split, es,
+                                                 (h == 0 ? 1 : 0) | (h == RF / CF - 1 ? 2 : 0));
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
         }
@@ -1034,6 +1054,185 @@ __global__ __launch_bounds__(640) void gemm_h192l_kernel(GemmArgs g) { gemm_huge
 #define Q_LDS 81920
 template <bool AKC, bool BKC, unsigned F>
 __global__ __launch_bounds__(256, 2) void gemm_q_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 4, 6, 128>(g); }
+
+// ------------------------------------------------------------------------------------------------------
+// Round 4: PERSISTENT form of the 256 (192) x 256 K-contiguous kernel with a specialised epilogue (the forward and input-gradient
+// GEMMs of the step).  One workgroup per CU walks the tile sequence w = blockIdx.x, + gridDim.x, ... (the same XCD-contiguous order as
+// the one-tile-per-workgroup kernels: gridDim.x is a multiple of 8, so a workgroup's tiles stay on its XCD's run).
+// For the operand DMA a tile boundary is just another k-step: the LAST k-iteration of a tile issues the first operand stage of the
+// NEXT tile into the stage that iteration does not read, so the ~2 us HBM / L2 round trip of a tile's prologue (measured: 18 us of a
+// 237 us launch on 45120 x 3072 x 768, 8.3 tiles per CU) lands under the last k-tile's MFMAs, and the epilogue runs without any
+// DMA wait -- its global stores are never waited for either (the next explicit vmcnt(0) is at the end of the next tile's first
+// k-iteration).  The stage holding the next tile's operands alternates when a tile has an odd number of k-steps (`sp`), and the
+// epilogue's wave-private staging slices (32-row chunks: 8 x 32 rows x 68 floats) live in whatever LDS that stage leaves free;
+// they may overlap the OTHER stage, which is only refilled after barrier (A) of the next tile, when every wave has left its epilogue.
+// LW > 0: loader waves issue every DMA (the 192-row tile, see gemm_h192l_kernel) and follow the same barrier sequence; the compute
+// waves then never execute a vmcnt wait at all.
+// Results are bit-identical to the one-tile kernels (same k order, same epilogue arithmetic).
+// ------------------------------------------------------------------------------------------------------
+#define PERS_LDS 139776                                   // stage 1 resident + seven slices below it + the eighth behind it: 131072 + 8704
+template <unsigned F, int RF, int LW>
+__device__ __forceinline__ void gemm_pers_body(const GemmArgs& g) {
+    static_assert(F != EF_ALL && F != EF_TNFLUSH, "persistent kernel: specialised epilogues only");
+    constexpr int NW = 8, WN = 4, NJ = 4;
+    constexpr int BMT = 2 * RF * 16;                      // tile rows
+    constexpr int NI = LW > 0 ? LW : NW;                  // waves that issue the operand DMA
+    constexpr int PA = BMT / 8 / NI, PB = 256 / 8 / NI;   // 1-KB pieces per issuing wave per A / B tile
+    constexpr int BOFF = 32768, STAGE = HUGE_STAGE;
+    constexpr int WS = 68, CF = 2;                        // epilogue chunk: 32 rows x 64 columns per wave, row stride 68 floats
+    constexpr int SLICE = CF * 16 * WS * 4;               // 8704 bytes
+    static_assert(7 * SLICE <= STAGE && 2 * STAGE + SLICE <= PERS_LDS && STAGE + NW * SLICE <= PERS_LDS, "epilogue slices vs stages");
+    static_assert(RF % CF == 0, "row fragments per epilogue chunk");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = g.N / 256, tiles_m = (g.M + BMT - 1) / BMT;
+    const int nwg = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int nk = g.K / BKT;
+    auto tile_of = [&](int w, int& m0, int& n0) {
+        int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
+        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        int tm = bid / tiles_n, tn = bid % tiles_n;
+        if (g.group_n > 0 && g.group_n < tiles_n) {
+            const int per = tiles_m * g.group_n, cg = bid / per, rem = bid - cg * per;
+            const int gw = min(g.group_n, tiles_n - cg * g.group_n);          // last group may be narrower
+            tm = rem / gw; tn = cg * g.group_n + rem % gw;
+        }
+        m0 = tm * BMT; n0 = tn * 256;
+    };
+    // operand DMA of the issuing waves: a lane's source rows are fixed over a tile's k-loop (A through the optional pair-expansion row map)
+    const bool issuer = LW > 0 ? wave >= NW : true;
+    const int li = LW > 0 ? wave - NW : wave;
+    const int sw = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
+    const bf16_t* ar[PA];
+    const bf16_t* br[PB];
+    auto set_src = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            int r = min(m0 + (li * PA + i) * 8 + (lane >> 3), g.M - 1);
+            if (g.e.a_rowmap) r = g.e.a_rowmap[r];
+            ar[i] = g.A + (long)r * g.lda + sw;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) br[i] = g.B + (long)min(n0 + (li * PB + i) * 8 + (lane >> 3), g.N - 1) * g.ldb + sw;
+    };
+    auto issue = [&](int stage, int kt) {
+        char* st = smem + stage * STAGE;
+        const int k0 = kt * BKT;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ar[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(st + (li * PA + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(br[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(st + BOFF + (li * PB + i) * 1024), 16, 0, 0);
+    };
+    int w = blockIdx.x, m0, n0;
+    int sp = 0;                                             // stage that holds k-tile 0 of the current tile
+    tile_of(w, m0, n0);
+    if (issuer) { set_src(m0, n0); if (nk > 0) issue(0, 0); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool skip_k = (g.dbg & 2) != 0;                   // probe: no k-loop (the next tile's first stage is still issued, at the tile boundary)
+
+    if constexpr (LW > 0) {
+        if (wave >= NW) {                                   // loader waves: DMA only, same barrier sequence as the compute waves
+            for (;;) {
+                const int wnext = w + G;
+                const bool more = wnext < nwg;
+                __builtin_amdgcn_s_barrier();               // (A)
+                for (int kt = 0; kt < (skip_k ? 0 : nk); ++kt) {
+                    const int st = (sp + kt) & 1;
+                    if (kt + 1 < nk) issue(st ^ 1, kt + 1);
+                    else if (more) { tile_of(wnext, m0, n0); set_src(m0, n0); issue(st ^ 1, 0); }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (skip_k) {
+                    if (more && nk > 0) { tile_of(wnext, m0, n0); set_src(m0, n0); issue((sp + nk) & 1, 0); }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (!more) return;
+                w = wnext; sp = (sp + nk) & 1;
+            }
+        }
+    }
+    const int wm = wave / WN, wn = wave % WN;
+    for (;;) {
+        f32x4 acc[RF][NJ];
+#pragma unroll
+        for (int i = 0; i < RF; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int wnext = w + G;
+        const bool more = wnext < nwg;
+        int m1 = 0, n1 = 0;
+        if (more) tile_of(wnext, m1, n1);
+        __builtin_amdgcn_s_barrier();                       // (A): every wave has left the previous epilogue (its slices may overlap the stage refilled next)
+        for (int kt = 0; kt < (skip_k ? 0 : nk); ++kt) {
+            const int st = (sp + kt) & 1;
+            const char* la = smem + st * STAGE;
+            const char* lb = la + BOFF;
+            if constexpr (LW == 0) {
+                if (kt + 1 < nk) issue(st ^ 1, kt + 1);
+                else if (more) { set_src(m1, n1); issue(st ^ 1, 0); }      // tile boundary: the next tile's first stage, under this k-tile's MFMAs
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[RF], fb[NJ];
+#pragma unroll
+                for (int i = 0; i < RF; ++i) fa[i] = frag_read<true>(la, wm * RF + i, ks, lane);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = frag_read<true>(lb, wn * NJ + j, ks, lane);
+#pragma unroll
+                for (int i = 0; i < RF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            if constexpr (LW == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const int X = (sp + nk) & 1;                        // stage that now holds the next tile's k-tile 0: off limits to the epilogue
+        if (skip_k) {
+            if constexpr (LW == 0) { if (more && nk > 0) { set_src(m1, n1); issue(X, 0); } asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            __builtin_amdgcn_s_barrier();
+        }
+        if (!(g.dbg & 1)) {
+            // wave-private slice: behind stage 0 when that is the resident stage, else seven slices in stage 0 and the eighth behind stage 1
+            const int soff = __builtin_amdgcn_readfirstlane(X == 0 ? STAGE + wave * SLICE : (wave < 7 ? wave * SLICE : 2 * STAGE));
+            float* clw = (float*)(smem + soff);
+            const int mc = m0 + wm * (RF * 16), nc = n0 + wn * 64;
+            EpiState es;
+#pragma unroll
+            for (int h = 0; h < RF / CF; ++h) {               // unrolled: acc[] must be indexed with compile-time constants
+                if (!(g.dbg & 4)) {
+#pragma unroll
+                    for (int i = 0; i < CF; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                clw[(i * 16 + (lane >> 4) * 4 + r) * WS + j * 16 + (lane & 15)] = acc[h * CF + i][j][r];
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the slice is only read by this wave
+                __builtin_amdgcn_wave_barrier();
+                gemm_epilogue<CF * 16, 64, F, 8, WS>(g, clw, mc + h * (CF * 16), nc, 0, es, (h == 0 ? 1 : 0) | (h == RF / CF - 1 ? 2 : 0));
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (!more) return;
+        w = wnext; m0 = m1; n0 = n1; sp = X;
+    }
+}
+template <unsigned F>
+__global__ __launch_bounds__(512) void gemm_p256_kernel(GemmArgs g) { gemm_pers_body<F, 8, 0>(g); }
+template <unsigned F>
+__global__ __launch_bounds__(640) void gemm_p192l_kernel(GemmArgs g) { gemm_pers_body<F, 6, 2>(g); }
+template <unsigned F>
+__global__ __launch_bounds__(512) void gemm_p192_kernel(GemmArgs g) { gemm_pers_body<F, 6, 0>(g); }      // fp32-output epilogue: does not fit the loader variant's 168 registers
 
 // ------------------------------------------------------------------------------------------------------
 // Ping-pong 256x256x32 kernels.  8 waves in two groups of four -- group g = wave >> 2 owns rows [128 g, 128 g + 128) of
@@ -1502,6 +1701,18 @@ static int lav_gemm_group_n = getenv("LAV_GEMM_GROUP_N") ? atoi(getenv("LAV_GEMM
 static int lav_gemm_h192 = getenv("LAV_GEMM_H192") ? atoi(getenv("LAV_GEMM_H192")) : 1;          // 192-row tiles for outputs that under-fill the last round of 256-row tiles
 static int lav_gemm_h192l = getenv("LAV_GEMM_H192L") ? atoi(getenv("LAV_GEMM_H192L")) : 1;                         // 192-row tiles: two loader waves issue the operand DMA (0 = off, 2 = probe: on every 256-column shape)
 static int lav_gemm_q = getenv("LAV_GEMM_Q") ? atoi(getenv("LAV_GEMM_Q")) : 0;                                     // 192x128 four-wave tiles, two workgroups per CU
+static int lav_gemm_pers = getenv("LAV_GEMM_PERS") ? atoi(getenv("LAV_GEMM_PERS")) : 0;                            // persistent tile-walking kernels (gemm_p256 / gemm_p192l) for the specialised K-contiguous launches
+static int lav_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount;
+        else { (void)hipGetLastError(); n = 256; }
+        n -= n % 8;                                          // a multiple of the XCD count: a workgroup's tiles stay on one XCD's run
+        if (n < 8) n = 8;
+    }
+    return n;
+}
 static int lav_gemm_dbg = getenv("LAV_GEMM_DBG") ? atoi(getenv("LAV_GEMM_DBG")) : 0;                               // probe hook: GemmArgs.dbg of the 256x256 kernel
 static int lav_gemm_pp_dbg = 0;                            // ablation builds of the ping-pong kernel (probe only, wrong results): 1 no refills, 2 no fragment reads, 4 no MFMAs
 extern "C" int lav_gemm_select(int which, int value) {    // probe hook (within-process A/B): which 0 = ping-pong kernel on/off; returns the old value
@@ -1514,6 +1725,7 @@ extern "C" int lav_gemm_select(int which, int value) {    // probe hook (within-
     if (which == 7) { old = lav_gemm_h192; lav_gemm_h192 = value; }
     if (which == 8) { old = lav_gemm_q; lav_gemm_q = value; }
     if (which == 9) { old = lav_gemm_h192l; lav_gemm_h192l = value; }
+    if (which == 10) { old = lav_gemm_pers; lav_gemm_pers = value; }
     return old;
 }
 
@@ -1618,6 +1830,25 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         else if (fsel == S_BDR) LAV_PP_ONE(S_BDR, GRID);                                                                  \
         else LAV_PP_ONE(S_BDRO, GRID);                                                                                    \
     } while (0)
+#define LAV_PERS_ONE(KERN, THREADS, F_, TILES)                                                                            \
+    do {                                                                                                                  \
+        static bool attr_done = false;                                                                                    \
+        if (!attr_done) {                                                                                                 \
+            hipFuncSetAttribute((const void*)KERN<F_>, hipFuncAttributeMaxDynamicSharedMemorySize, PERS_LDS);             \
+            (void)hipGetLastError();                                                                                      \
+            attr_done = true;                                                                                             \
+        }                                                                                                                 \
+        const long ncu_ = lav_num_cus();                                                                                  \
+        hipLaunchKernelGGL((KERN<F_>), dim3((unsigned)((TILES) < ncu_ ? (TILES) : ncu_)), dim3(THREADS), PERS_LDS, s, g); \
+    } while (0)
+#define LAV_LAUNCH_PERS(KERN, THREADS, TILES)                                                                             \
+    do {                                                                                                                  \
+        if (fsel == S_B) LAV_PERS_ONE(KERN, THREADS, S_B, TILES);                                                         \
+        else if (fsel == S_BG) LAV_PERS_ONE(KERN, THREADS, S_BG, TILES);                                                  \
+        else if (fsel == S_GC) LAV_PERS_ONE(KERN, THREADS, S_GC, TILES);                                                  \
+        else if (fsel == S_BDR) LAV_PERS_ONE(KERN, THREADS, S_BDR, TILES);                                                \
+        else LAV_PERS_ONE(KERN, THREADS, S_BDRO, TILES);                                                                  \
+    } while (0)
     // pick the tile by estimated machine fill: tiles / (rounds * resident slots), weighted by the tile's own efficiency
     auto fill = [](long tiles, long slots, double w) { return w * (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
     const long t_small = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -1636,7 +1867,9 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         const int tn_ = N / 256;
         g.group_n = lav_gemm_group_n >= 0 ? lav_gemm_group_n : (tn_ >= 8 && tn_ % 4 == 0 ? 4 : 0);
         dim3 hgrid((unsigned)t_huge);
-        LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
+        g.dbg = lav_gemm_dbg;
+        if (lav_gemm_pers && fsel != EF_ALL) LAV_LAUNCH_PERS(gemm_p256_kernel, 512, t_huge);
+        else LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
         return lav_check_launch("lav_gemm_bf16");
     }
     if (big && lav_gemm_h192l == 2 && layout == 0 && fsel != EF_ALL && (N % 256) == 0 && !g.e.a_rowmap) {     // probe: loader-wave tiles everywhere
@@ -1667,6 +1900,11 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         g.k_per_split = K;
         g.dbg = lav_gemm_dbg; g.group_n = 0;
         dim3 hgrid((unsigned)t_h192);
+        if (layout == 0 && lav_gemm_h192l && lav_gemm_pers) {
+            if (fsel == S_BDRO) LAV_PERS_ONE(gemm_p192_kernel, 512, S_BDRO, t_h192);
+            else LAV_LAUNCH_PERS(gemm_p192l_kernel, 640, t_h192);
+            return lav_check_launch("lav_gemm_bf16");
+        }
 #define LAV_H192(F_) { if (layout == 0 && lav_gemm_h192l) LAV_LAUNCH_ONE(gemm_h192l_kernel, true, true, F_, hgrid, HUGE_LDS); else if (layout == 0) LAV_LAUNCH_ONE(gemm_h192_kernel, true, true, F_, hgrid, HUGE_LDS); else LAV_LAUNCH_ONE(gemm_h192_kernel, true, false, F_, hgrid, HUGE_LDS); }
         if (fsel == S_B) LAV_H192(S_B) else if (fsel == S_BG) LAV_H192(S_BG) else if (fsel == S_GC) LAV_H192(S_GC)
         else if (fsel == S_BDR) LAV_H192(S_BDR) else LAV_H192(S_BDRO)
@@ -1702,6 +1940,10 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         if (layout != 2) {
             const int tn_ = N / 256;
             g.group_n = lav_gemm_group_n >= 0 ? lav_gemm_group_n : (tn_ >= 8 && tn_ % 4 == 0 ? 4 : 0);
+        }
+        if (layout == 0 && lav_gemm_pers && fsel != EF_ALL) {
+            LAV_LAUNCH_PERS(gemm_p256_kernel, 512, t_huge);
+            return lav_check_launch("lav_gemm_bf16");
         }
         LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
         return lav_check_launch("lav_gemm_bf16");
@@ -1743,6 +1985,12 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         const bool large_ok = plain && (K % BKT) == 0 && (kps % BKT) == 0 && M >= 256 && !lav_gemm_force_small &&
                               (!g.e.k_keep || g.e.k_rows_per_group >= BKT);
         if (large_ok && lav_gemm_tn_kind != 0) kind = (N % 256) == 0 && lav_gemm_tn_kind != 1 ? 2 : 1;
+        // contraction lengths that are multiples of 32 but not of 64 (Swin stage 3: 7840 token rows): the ping-pong kernel walks k-tiles of 32
+        // (k_per_split is a multiple of 64, so only the last split ends on a 32-boundary) -- before round 4 these fell to the 128 x 128 kernel
+        const bool pp_only = !large_ok && plain && (K % PP_BK) == 0 && (K % BKT) != 0 && M >= 256 && (N % 256) == 0 && !lav_gemm_force_small &&
+                             lav_gemm_pp_tn && lav_gemm_tn_kind != 0 && lav_gemm_tn_kind != 1 &&
+                             (!g.e.k_keep || (g.e.k_rows_per_group >= BKT && (K + g.e.k_rows_per_group - 1) / g.e.k_rows_per_group <= 128));
+        if (pp_only) kind = 2;
         const int rpt = kind ? BIG_BM : BM;
         const int ws_tiles = ((M + rpt - 1) / rpt) * ((N + BN - 1) / BN);
         bool reduce = false;

@@ -659,6 +659,7 @@ extern "C" void lav_decoder_destroy(void* h) {
 extern "C" int lav_decoder_decode(void* h, void* stream, int n_frames, const char* const* b64, const long* b64_len, const lav_frame_xform* xf,
                                   int out_h, int out_w, const float* mean3, const float* std3, float* out) {
     Decoder* D = (Decoder*)h;
+    if (D) D->failed.clear();                               // before any early return: lav_decoder_failed_frames() describes THIS call only
     LAV_REQUIRE(D && n_frames > 0 && b64 && b64_len && xf && out_h > 0 && out_w > 0 && mean3 && std3 && out, "lav_decoder_decode: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     // ---- host stage 1 (threads): base64 + header ------------------------------------------------------------------
@@ -683,7 +684,6 @@ extern "C" int lav_decoder_decode(void* h, void* stream, int n_frames, const cha
         const char* e = jpeg_parse(jpg[i].data(), n, hdr[i], true);
         if (e) err[i] = e;
     });
-    D->failed.clear();
     auto report = [&]() {                                   // every unreadable frame of the batch, first message
         int first = -1;
         for (int i = 0; i < n_frames; ++i)

@@ -66,8 +66,8 @@ class ArenaReducer:
         self.rank = dist.get_rank(group)
         self.bucket_elems = max(64, int(bucket_mb * (1 << 20) // 4) // 64 * 64)     # 64-element multiples: bucket edges stay 16-byte aligned in bf16
         a = model.arena()
-        # identical initial parameters on every rank (DDP broadcasts from rank 0 at wrap time)
-        dist.broadcast(a.master, src=0, group=group)
+        # identical initial parameters on every rank (DDP broadcasts from rank 0 at wrap time); src is a GLOBAL rank
+        dist.broadcast(a.master, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
         a.sync_half()
         self._stream = torch.cuda.Stream() if a.master.is_cuda else None
         self._done = []          # [lo, hi) ranges already reduced in this step
@@ -253,7 +253,10 @@ class ZeroOneReducer(ArenaReducer):
         return out[::-1]
 
     def _exchange(self, t, b0, **kw):
-        return dist.reduce(t, dst=b0 // self.shard, op=dist.ReduceOp.SUM, group=self.group, **kw)
+        # dist.reduce(dst=) takes a GLOBAL rank; the shard owner b0 // shard is an index inside self.group
+        owner = b0 // self.shard
+        dst = owner if self.group is None else dist.get_global_rank(self.group, owner)
+        return dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=self.group, **kw)
 
     def _widen_back(self):
         self._widen = [(b0, b1) for b0, b1 in self._widen if self.lo <= b0 < self.hi]      # only the own shard's sums are used
@@ -280,9 +283,11 @@ class ZeroOneReducer(ArenaReducer):
 
     def gather_master(self):
         """fp32 masters of every shard on every rank (before state_dict() / a checkpoint)."""
+        a = self.model.arena()
+        if self._master_stale and not getattr(a, "masters_sharded", True):
+            self._master_stale = False                         # a full load_state_dict since the last sharded step made the masters whole
         if not self._master_stale:
             return
-        a = self.model.arena()
         full = torch.zeros(self.padded, dtype=torch.float32, device=a.master.device)
         full[self.lo:self.hi].copy_(a.master[self.lo:self.hi])
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)

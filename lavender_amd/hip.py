@@ -94,7 +94,7 @@ def splits_for(M, N, K, keep=False):
     when M >= 256, N % 256 == 0 and K % 64 == 0; 256x128 when only N % 256 fails; else 128x128).  Measured on MI355X
     (tools/tn_probe.py): every variant holds one block per CU and is fastest when tiles x splits lands just under 256;
     partial tiles go to a workspace and are summed by one reduction pass, so extra splits are cheap."""
-    if M >= 256 and K % 64 == 0:
+    if M >= 256 and (K % 64 == 0 or (K % 32 == 0 and N % 256 == 0)):
         tiles = ((M + 255) // 256) * (N // 256 if N % 256 == 0 else (N + 127) // 128)
         return int(max(1, min(_TN_BLOCKS // tiles if tiles <= _TN_BLOCKS else 1, K // 256)))
     tiles = ((M + 127) // 128) * ((N + 127) // 128)

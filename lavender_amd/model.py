@@ -126,12 +126,17 @@ class LAVENDER_Base(nn.Module):
             self.true_token_id = self.tokzr.convert_tokens_to_ids(["true"])[0]
             self.false_token_id = self.tokzr.convert_tokens_to_ids(["false"])[0]
         self._lav_arena = None
-        self.register_load_state_dict_post_hook(lambda m, k: m._mark_stale())
+        self.register_load_state_dict_post_hook(lambda m, k: m._mark_stale(k))
 
     # ---- arena ---------------------------------------------------------------------------------
-    def _mark_stale(self):
-        if self._lav_arena is not None:
-            self._lav_arena.stale = True
+    def _mark_stale(self, keys=None):
+        a = self._lav_arena
+        if a is not None:
+            a.stale = True
+            # a FULL load (no arena parameter missing from the state dict) rewrote every fp32 master on this rank: the masters
+            # are whole again even if a ZeRO-1 step had sharded them (dp.ZeroOneReducer.gather_master then has nothing to do)
+            if keys is not None and not any(k in a.offsets for k in getattr(keys, "missing_keys", ())):
+                a.masters_sharded = False
 
     def arena(self):
         a = self._lav_arena

@@ -81,8 +81,9 @@ class Agent_Pretrain(Agent_Base):
 
     def save_model(self, ep, dataset="init", part=0):
         """main_pretrain_task_specific.py:282-297: one checkpoint per (dataset, part, epoch) of the pre-training loop,
-        ckpt_violet_pretrain_{dataset}_{part}_{ep}.pt -- the names the downstream configs of the reference load."""
-        self._save_state(f"ckpt_violet_pretrain_{dataset}_{part}_{ep}.pt")
+        ckpt_violet_pretrain_{dataset}_{part}_{ep}.pt -- the names the downstream configs of the reference load -- and, as in
+        the reference, nothing else (no log.json).  Call on EVERY rank: under ZeRO-1 the masters are gathered collectively first."""
+        self._save_state(f"ckpt_violet_pretrain_{dataset}_{part}_{ep}.pt", write_log=False)
 
     def masking(self, txt, mask, p_mask=0.15):
         """main_pretrain_task_specific.py:186-209 (same procedure as the MLM agent)."""

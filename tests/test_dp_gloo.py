@@ -199,3 +199,57 @@ def test_zero1_matches_replicated_adamw_world2():
         p.join(timeout=60)
     assert [r[:2] for r in res] == [(0, True), (1, True)]
     assert res[0][2] == res[1][2]                               # identical parameters on both ranks after gather_master()
+
+
+def _subgroup_worker(rank, world, port, q):
+    """ZeRO-1 inside a process SUB-GROUP {1, 2} of a 3-rank world: shard owners are group-local indices, dist.reduce / broadcast
+    take global ranks -- every bucket must still reach the rank that owns it (lavender_amd/dp.py ZeroOneReducer._exchange)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grp = dist.new_group([1, 2])                                # collective over the whole world, members or not
+    if rank == 0:
+        q.put((rank, True, 0.0))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    from lavender_amd.dp import ArenaReducer, ZeroOneReducer
+    total = 64 * 101
+    lr4, wd4 = [1e-2] * 4, [1e-3] * 4
+    outs = {}
+    for kind in ("ddp", "zero1"):
+        arena = _MockArena(total, rank)
+        arena.names = ["trsfr.a"]
+        arena.span = lambda ns: (64 * 5, 64 * 90)
+        model = types.SimpleNamespace(arena=lambda a=arena: a)
+        red = (ZeroOneReducer if kind == "zero1" else ArenaReducer)(model, group=grp)
+        for step in (1, 2):
+            arena.grad_full.zero_()
+            arena.grad.copy_(torch.randn(total, generator=torch.Generator().manual_seed(100 * step + rank)))
+            red.begin_step()
+            for f in arena.listeners:
+                f("fusion_grads_final")
+            red.finish()
+            red.optimizer_step(arena, lr4, wd4, step, 1.0, (0.9, 0.98), 1e-8)
+        red.gather_master()
+        outs[kind] = (arena.master.clone(), arena.half.clone())
+    ok = bool(torch.allclose(outs["ddp"][0], outs["zero1"][0], atol=1e-6)) and bool(torch.equal(outs["ddp"][1], outs["zero1"][1]))
+    # the broadcast came from the group's first member (global rank 1), whose masters start at randn * 0.1 + 1.0
+    ok &= abs(float(outs["ddp"][0].mean()) - 1.0) < 0.2
+    q.put((rank, ok, float(outs["zero1"][0].double().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero1_in_a_process_subgroup_world3():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert [r[:2] for r in res] == [(0, True), (1, True), (2, True)]
+    assert res[1][2] == res[2][2]

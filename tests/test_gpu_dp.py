@@ -172,3 +172,80 @@ def test_reducer_over_rccl_single_rank():
                 pytest.fail(f"RCCL worker failed (exit code {p.exitcode})")
     p.join(timeout=60)
     assert res is True
+
+
+def _rccl_variant_worker(port, q, zero, bf16):
+    """One RCCL rank through the branches that only run on the real backend: ZeroOneReducer's per-bucket dist.reduce(dst = owner)
+    over ProcessGroupNCCL, its all_gather_into_tensor of the bf16 working copy (dp.py `self._nccl`), gather_master(), the
+    full-load reset of the sharded flag, and the bf16 gradient buckets (cast on the comm stream, widened back at finish()).
+    At one rank every collective is a copy, so the result must equal the plain single-process step."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import lavender_amd as LA
+    from lavender_amd.dp import ArenaReducer, ZeroOneReducer
+    from tests.helpers import Tok, make_args
+    ok = True
+    finals = {}
+    for with_dp in (False, True):
+        torch.manual_seed(7)
+        m = LA.LAVENDER_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3), Tok()).cuda()
+        m.arena()
+        agent = LA.Agent_Pretrain_MLM(make_args("micro", "micro", 2, lr=1e-3, deepspeed=zero, grad_comm_bf16=bf16), m)
+        if with_dp:
+            agent.dp = (ZeroOneReducer if zero else ArenaReducer)(m, grad_dtype="bf16" if bf16 else "fp32")
+            agent.dp.HALF_MIN_ELEMS = 4096
+            ok &= agent.dp._nccl if zero else True
+            agent.dp.begin_step()
+        g = _rank_grads(0, agent, m)
+        if with_dp:
+            done_early = sorted(agent.dp._done)
+            ok &= len(done_early) > 0                      # the overlapped exchange fired during the backward
+            agent.dp.finish()
+            if bf16:                                        # the widened bf16 sums are within bf16 rounding of the local gradient
+                g2 = m.arena().grad
+                ok &= bool(((g2 - g).norm() / g.norm()).item() < 1e-2)
+        agent.optzr.step(max_norm=1.0, dp=agent.dp)
+        if with_dp and zero:
+            ok &= m.arena().masters_sharded
+            agent.dp.gather_master()
+            ok &= not m.arena().masters_sharded
+            # a second sharded step, then a FULL load_state_dict: the masters are whole again without a gather (arena.py masters_sharded)
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            agent.dp.begin_step(); _rank_grads(0, agent, m); agent.dp.finish()
+            agent.optzr.step(max_norm=1.0, dp=agent.dp)
+            ok &= m.arena().masters_sharded
+            m.load_state_dict(sd)
+            ok &= not m.arena().masters_sharded
+            m.arena().sync_half_if_stale()
+            agent.dp.gather_master()                        # nothing to do, must not raise
+        torch.cuda.synchronize()
+        finals[with_dp] = (m.arena().master.clone(), m.arena().half.clone())
+    tol = 2e-3 if bf16 else 1e-6
+    ok &= bool(((finals[True][0] - finals[False][0]).abs().max() <= tol).item())
+    ok &= bool(torch.equal(finals[True][1].float(), finals[True][0].bfloat16().float()))
+    q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("zero,bf16", [(True, False), (False, True), (True, True)])
+def test_zero1_and_bf16_buckets_over_rccl_single_rank(zero, bf16):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_variant_worker, args=(29800 + (os.getpid() % 1000) + 3 * zero + 7 * bf16, q, zero, bf16))
+    p.start()
+    import queue as _queue
+    import time as _time
+    t0, res = _time.time(), None
+    while res is None:
+        try:
+            res = q.get(timeout=2)
+        except _queue.Empty:
+            if p.exitcode not in (None, 0) or _time.time() - t0 > 240:
+                if p.is_alive():
+                    p.terminate()
+                pytest.fail(f"RCCL worker failed (exit code {p.exitcode})")
+    p.join(timeout=60)
+    assert res is True

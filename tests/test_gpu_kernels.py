@@ -62,6 +62,75 @@ def test_gemm_large_m_kernels(layout, shape):
     close(cs, ref.sum(0), atol=2.0, rtol=2e-2, what="colsum")
 
 
+@pytest.mark.parametrize("shape,flags", [((8448, 2048, 128), "bGp"), ((8448, 2048, 192), "bdrO"), ((45120, 768, 128), "bdr"),
+                                         ((45120, 768, 64), "gsc"), ((70000, 256, 64), "b")])
+def test_gemm_persistent_tile_walk(shape, flags):
+    """Round 4: outputs with more 256 (192) x 256 tiles than CUs run the PERSISTENT kernels (gemm_p256 / gemm_p192l: one workgroup per
+    CU walks several tiles, the next tile's first operand stage is in flight under the current epilogue, the epilogue stages through
+    the LDS behind it).  Against the fp32 reference, and bit-identical to the one-tile-per-workgroup kernels (lav_gemm_select(10, 0))."""
+    from lavender_amd import _lib as L
+    M, N, Kd = shape
+    A, W = rb(M, Kd), rb(N, Kd, seed=1, scale=0.2)
+    o32 = "O" in flags
+    kw = {}
+    if "b" in flags: kw["bias"] = torch.randn(N).cuda()
+    if "G" in flags: kw["act"] = 1
+    if "g" in flags: kw["gelu_in"] = rb(M, N, seed=5).abs(); kw["gelu_in_is_grad"] = 1
+    if "d" in flags: kw["dropout_p"] = 0.1; kw["seed"] = 4321
+    if "s" in flags: kw["row_scale"] = (torch.tensor([1.25, 0.0, 1.25, 1.25] * 8)).cuda(); kw["rows_per_group"] = (M + 31) // 32
+    if "r" in flags: kw["residual"] = rb(M, N, seed=2).float() if o32 else rb(M, N, seed=2)
+    res = {}
+    for mode in (1, 0):
+        old = L.lib.lav_gemm_select(10, mode)
+        try:
+            k2 = dict(kw)
+            if "p" in flags: k2["preact"] = torch.zeros(M, N, dtype=bf16, device="cuda"); k2["preact_is_grad"] = 1
+            if "c" in flags: k2["colsum"] = torch.zeros(N, device="cuda")
+            out = K().gemm(0, A, W, M, N, Kd, out_dtype=torch.float32 if o32 else bf16, **k2)
+            torch.cuda.synchronize()
+        finally:
+            L.lib.lav_gemm_select(10, old)
+        res[mode] = (out, k2.get("preact"), k2.get("colsum"))
+    assert torch.equal(res[0][0], res[1][0]), "persistent vs one-tile kernels differ"
+    if res[0][1] is not None:
+        assert torch.equal(res[0][1], res[1][1])
+    z = A.float() @ W.float().t()
+    if "b" in flags: z = z + kw["bias"]
+    if flags in ("bGp",):
+        hh = z.detach().clone().requires_grad_(True)
+        y = F.gelu(hh); y.sum().backward()
+        close(res[1][0], y.detach(), atol=3e-2, what="persistent gelu")
+        close(res[1][1], hh.grad, atol=3e-2, what="persistent stored gelu'")
+    elif flags == "b":
+        close(res[1][0], z, atol=3e-2, what="persistent bias")
+    elif flags == "gsc":
+        ref = z * kw["gelu_in"].float() * kw["row_scale"].repeat_interleave(kw["rows_per_group"])[:M, None]
+        close(res[1][0], ref, atol=3e-2, what="persistent gelu' x row scale")
+        close(res[1][2], ref.sum(0), atol=2.0, rtol=2e-2, what="persistent colsum")
+        close(res[0][2], ref.sum(0), atol=2.0, rtol=2e-2, what="one-tile colsum")
+    else:                                                  # dropout: the kept elements are (z / 0.9 + residual), the dropped ones the residual
+        o, r = res[1][0].float(), kw["residual"].float()
+        kept = (o - r).abs() > 0
+        assert 0.88 < kept.float().mean().item() < 0.92
+        close(torch.where(kept, o, r + z / 0.9), r + z / 0.9, atol=3e-2, what="persistent dropout + residual")
+
+
+@pytest.mark.parametrize("splits", [1, 3])
+def test_gemm_tn_contraction_multiple_of_32(splits):
+    """Swin stage 3 has 7840 token rows (= 245 x 32, not a multiple of 64): the weight-gradient GEMM takes the ping-pong 256 x 256
+    kernel (k-tiles of 32) instead of the 128 x 128 one; drop-path groups of 245 rows straddle k-tiles."""
+    M, N, Kd = 1024, 512, 7840
+    dY, X = rb(Kd, M), rb(Kd, N, seed=1)
+    keep = torch.tensor([1.25, 0.0, 1.25, 0.0] * 8, device="cuda")
+    dW = torch.zeros(M, N, device="cuda")
+    db = torch.zeros(M, device="cuda")
+    K().gemm(2, dY, X, M, N, Kd, out=dW, accumulate=True, splits=splits, k_keep=keep, k_rows_per_group=245, alpha=1.25, rowsum_a=db)
+    m = (keep != 0).float().repeat_interleave(245)[:Kd, None].cpu()
+    ref = 1.25 * (dY.float().cpu() * m).t() @ X.float().cpu()
+    close(dW, ref, atol=0.5, rtol=1e-2, what="dW, K = 245 x 32")
+    close(db, 1.25 * (dY.float().cpu() * m).sum(0), atol=0.5, rtol=1e-2, what="fused bias gradient")
+
+
 def test_gemm_epilogue_bias_gelu_preact_residual_rowscale():
     M, N, Kd = 300, 264, 128
     A, W, res = rb(M, Kd), rb(N, Kd, seed=1, scale=0.1), rb(M, N, seed=2)
