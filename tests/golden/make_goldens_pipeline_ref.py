@@ -4,7 +4,7 @@ The reference's `dataset.Dataset_Base` imports here with the same stub recipe ma
 torchvision are absent: `str2img` then takes the reference's own `except` branch (PIL), and the clip transforms of
 visbackbone/video_transform.py need neither).  This script runs the REFERENCE's
     sampling / temporal_sample (dataset.py:188-216), str2img (:177-186), vid_center_crop / vid_rand_crop (:132-162),
-    get_img_or_video (:218-256, img_transform == ["vid_rand_crop"], train seeded and val; and a two-entry list, which pins the draw
+    get_img_or_video (:218-256, img_transform == ["vid_rand_crop"], train seeded and val; and a three-entry list, which pins the draw
     order of random.choice at :225)
 on the two fixture rows of msrvtt_2rows.tsv and writes their outputs to pipeline_ref_pin.npz.  tests/test_oracle_golden.py holds
 oracle/pipeline_ref.py to these vectors; tests/test_gpu_pipeline.py holds the HIP pipeline to the oracle.
@@ -62,7 +62,7 @@ def main():
 
     res = {}
     d_train, d_val = ds("train", 4, ["vid_rand_crop"]), ds("val", 4, ["vid_rand_crop"])
-    d_train2 = ds("train", 4, ["vid_rand_crop", "vid_rand_crop"])
+    d_train2 = ds("train", 4, ["vid_rand_crop", "vid_rand_crop", "vid_rand_crop"])
     # ---- integer paths: sampling / temporal_sample ----------------------------------------------------------------------
     grid = [(s, e, n) for s in (0, 1, 3) for e in (3, 4, 9, 31, 100) for n in (1, 2, 3, 4, 5, 8) if e >= s]
     res["sampling_args"] = np.array(grid, dtype=np.int64)
@@ -102,18 +102,18 @@ def main():
         res[f"ref_sample_train_{r}_shape"] = np.array(x.shape, dtype=np.int64)
         x = d_val.get_img_or_video(frames).numpy()
         res[f"ref_sample_val_{r}_sub"], res[f"ref_sample_val_{r}_sum"] = sub(x), sums(x)
-        # a TWO-entry transform list: random.choice (dataset.py:225) then draws from the same `random` stream per frame, between the
-        # temporal sampling and the crop offsets -- with one entry it consumes getrandbits(1) draws, with two getrandbits(2) draws, so
-        # the crop that follows differs: this pins the draw ORDER of the choice itself.  (Only lists of 'vid_rand_crop' are runnable
+        # a THREE-entry transform list: random.choice (dataset.py:225) then draws from the same `random` stream per frame, between the
+        # temporal sampling and the crop offsets -- one or two entries reject a 32-bit draw when its top bit is set, three entries when its top TWO bits are
+        # set, so the number of draws consumed -- and the crop that follows -- differs: this pins the draw ORDER of the choice itself.  (Only lists of 'vid_rand_crop' are runnable
         # here: every other train-mode entry calls torchvision, and a mixed list would cat PIL images with tensors in the reference.)
         random.seed(33 + r)
         x2 = d_train2.get_img_or_video(frames).numpy()
         res[f"ref_sample_train2_{r}_sub"], res[f"ref_sample_train2_{r}_sum"] = sub(x2), sums(x2)
         random.seed(33 + r)
-        y2 = PR.get_img_or_video(frames, 4, 224, ["vid_rand_crop", "vid_rand_crop"], "train", random, None).numpy()
+        y2 = PR.get_img_or_video(frames, 4, 224, ["vid_rand_crop", "vid_rand_crop", "vid_rand_crop"], "train", random, None).numpy()
         random.seed(33 + r)
         y1 = PR.get_img_or_video(frames, 4, 224, ["vid_rand_crop"], "train", random, None).numpy()
-        print(f"row {r}: two-entry list: oracle vs reference max|d| {np.abs(x2 - y2).max():.3g}; differs from the one-entry draw: {not np.array_equal(y1, y2)}")
+        print(f"row {r}: three-entry list: oracle vs reference max|d| {np.abs(x2 - y2).max():.3g}; differs from the one-entry draw: {not np.array_equal(y1, y2)}")
         assert np.array_equal(x2, y2)
         # self-check while the reference is in memory: the oracle must agree exactly
         random.seed(9 + r)

@@ -391,6 +391,6 @@ def test_pipeline_oracle_against_the_reference_dataset_class(golden_dir):
         assert list(x.shape) == g[f"ref_sample_train_{r}_shape"].tolist()
         same(x, f"ref_sample_train_{r}")
         same(PR.get_img_or_video(frames, 4, 224, ["vid_rand_crop"], "val", random, None), f"ref_sample_val_{r}")
-        # two-entry transform list: random.choice (dataset.py:225) draws from the same stream between the frame sampling and the crop
+        # three-entry transform list: random.choice (dataset.py:225) draws from the same stream between the frame sampling and the crop
         random.seed(33 + r)
-        same(PR.get_img_or_video(frames, 4, 224, ["vid_rand_crop", "vid_rand_crop"], "train", random, None), f"ref_sample_train2_{r}")
+        same(PR.get_img_or_video(frames, 4, 224, ["vid_rand_crop", "vid_rand_crop", "vid_rand_crop"], "train", random, None), f"ref_sample_train2_{r}")
