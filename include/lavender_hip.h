@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 const char* lav_last_error(void);
-int lav_abi_version(void);   /* 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
+int lav_abi_version(void);   /* 4: lav_gemm_epilogue.c_pad_writable; 3: a_rowmap / res_rowmap / res_ln_*; 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM with fused epilogue.  Replaces every nn.Linear on the path (video_swin.py:73-79,137-139,
@@ -79,13 +79,24 @@ typedef struct lav_gemm_epilogue {
     const float* res_ln_rstd; /* LayerNorm(residual) = (r - mean[row]) * rstd[row] * gamma[col] + beta[col] -- the same arithmetic as          */
     const float* res_ln_gamma;/* lav_layernorm_fwd, so the fp32 copy of a LayerNorm output that only feeds the next residual add              */
     const float* res_ln_beta; /* (post-LN BERT: BertSelfOutput / BertOutput) is never written: 138 MB per LayerNorm at the cfg2 shape         */
+    int hm_heads;             /* > 0 (bf16 output, N % (hm_heads * hm_head_dim) == 0, hm_head_dim % 8 == 0): HEAD-MAJOR store -- element (row, col) goes
+                                 to C[((col / HW) * hm_heads + (col % HW) / hm_head_dim) * hm_rows + row) * hm_head_dim + col % hm_head_dim], HW = hm_heads *
+                                 hm_head_dim: the fused q | k | v projection of WindowAttention3D (video_swin.py:145-150) written as [q|k|v][head][row][dim], the
+                                 layout the window-attention kernels fetch in whole lines (lav_attn_desc.qkv_headmajor).  ldc is ignored */
+    int hm_head_dim;
+    long hm_rows;             /* rows of one (plane, head) block, >= M */
+    int c_pad_writable;       /* N % 8 != 0 and ldc >= N rounded up to 8: the caller allows columns [N, round_up(N, 8)) of C to be overwritten
+                                 with unspecified values (layout 0, bf16 output, bias-only epilogue): the product then runs with full 16-byte
+                                 chunks instead of the ragged-N generic epilogue (the 30522-wide vocabulary projection of BertOnlyMLMHead,
+                                 main_pretrain_mlm.py:46-48, into its 30528-wide logits buffer).  B and bias are still read for N entries only */
 } lav_gemm_epilogue;
 
 int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                   void* C, long ldc, const lav_gemm_epilogue* epi, int splits);
-/* Tuning / probe hook: selects between kernel variants of lav_gemm_bf16 at run time (within-process A/B measurements);
- * which 0 = the ping-pong 256x256x32 kernel for large NT problems (value 0 / 1).  Returns the previous value, -1 for an
- * unknown selector.  Results are identical up to fp32 summation order. */
+/* Tuning / probe hook: selects between kernel variants at run time (within-process A/B measurements in tools/): which 2 = ping-pong
+ * weight-gradient kernel on/off, 5 = probe bits of the 256x256 kernel (timing only, wrong results), 6 = column-group width of the tile
+ * walk, 7 / 9 = 192-row tiles / their loader-wave form on/off, 16-18 = window-attention variants.  Returns the previous value, -1 for
+ * an unknown selector.  Results are identical up to fp32 summation order (except selector 5). */
 int lav_gemm_select(int which, int value);
 
 /* ---------------------------------------------------------------------------------------------
@@ -185,6 +196,9 @@ typedef struct lav_attn_desc {
                                  LAVENDER_Base.get_attn_mask (model.py:208-218) with this many prefix (video / pre-text) keys:
                                  prefix keys follow key_mask for every query, text keys are causal among the text queries
                                  and invisible to the prefix queries */
+    int qkv_headmajor;        /* window mode with the precomputed tables (comb != NULL) only: the qkv operand is laid out
+                                 [q | k | v][head][token row][head_dim] (as lav_gemm_epilogue.hm_heads writes it) instead of row-major
+                                 (rows, 3 * heads * head_dim); a window's operand pieces are then whole 128-byte lines.  dqkv stays row-major */
 } lav_attn_desc;
 
 int lav_attention_fwd(void* stream, const lav_attn_desc* d, const void* qkv, void* out, float* lse);

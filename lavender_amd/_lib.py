@@ -30,7 +30,7 @@ class GemmEpilogue(C.Structure):
                 ("ldr", i64), ("colsum", vp), ("alpha", f32), ("out_mode", i32), ("k_keep", vp),
                 ("k_rows_per_group", i32), ("rowsum_a", vp), ("preact_is_grad", i32), ("gelu_in_is_grad", i32),
                 ("residual_f32", i32), ("a_rowmap", vp), ("res_rowmap", vp),
-                ("res_ln_mean", vp), ("res_ln_rstd", vp), ("res_ln_gamma", vp), ("res_ln_beta", vp)]
+                ("res_ln_mean", vp), ("res_ln_rstd", vp), ("res_ln_gamma", vp), ("res_ln_beta", vp), ("hm_heads", i32), ("hm_head_dim", i32), ("hm_rows", i64), ("c_pad_writable", i32)]
 
 
 class LnGather(C.Structure):
@@ -51,7 +51,7 @@ class AttnDesc(C.Structure):
                 ("wd", i32), ("wh", i32), ("ww", i32), ("sd", i32), ("sh", i32), ("sw", i32), ("cfg_wh", i32),
                 ("cfg_ww", i32), ("cfg_wd", i32), ("bias_table", vp), ("n_seq", i32), ("L", i32), ("key_mask", vp),
                 ("dropout_p", f32), ("seed", u32), ("scale", f32), ("tok_table", vp), ("win_type", vp), ("type_region", vp),
-                ("n_types", i32), ("comb", vp), ("combT", vp), ("causal_from", i32)]
+                ("n_types", i32), ("comb", vp), ("combT", vp), ("causal_from", i32), ("qkv_headmajor", i32)]
 
 
 P = C.POINTER

@@ -120,6 +120,19 @@ class Agent_Base:
             g["names"].append(n)
         return ArenaAdamW(self._unwrapped(), groups)
 
+    def _set_mode(self, is_train):
+        """self.model.train() / .eval() as the reference's step() does on every call (main_pretrain_mlm.py:146) -- but nn.Module.train()
+        walks and re-assigns all ~425 modules each time (1.6 ms of launch-thread time per step); the flags are only rewritten when some
+        module actually is in the other mode (the module list is cached: the model's structure does not change under an agent)."""
+        mods = self.__dict__.get("_mode_modules")
+        if mods is None:
+            mods = self.__dict__["_mode_modules"] = list(self.model.modules())
+        is_train = bool(is_train)
+        for m in mods:
+            if m.training != is_train:
+                self.model.train(is_train)
+                break
+
     def reduce_mean(self, v):
         """agent.py:145-153."""
         world_size = get_world_size()

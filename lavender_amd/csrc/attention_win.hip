@@ -77,6 +77,30 @@ __device__ __forceinline__ unsigned dma_off(const int* srel_l, int t, int lane, 
     return (unsigned)((rel * ld + col0 + lslot * 8) * 2);
 }
 
+// Where a (head, q / k / v) slice of the qkv operand lives (round 4).  Row-major (M, 3C), as the QKV GEMM stores it by default: a
+// token's slice is 64 bytes inside its 6C-byte row -- HALF a 128-byte line, the other half belongs to the neighbouring head and is
+// fetched again by another workgroup.  Head-major [q | k | v][head][token][32] (lav_attn_desc.qkv_headmajor, written that way by the
+// QKV GEMM epilogue: lav_gemm_epilogue.hm_*): a token's slice is still 64 bytes, but consecutive tokens of a window row follow each
+// other, so a window's DMA pieces are runs of ww x 64 contiguous bytes = whole lines that this workgroup alone uses.
+//   rs   = elements between consecutive token rows;  col0 = element offset of the head's q slice at token row 0;
+//   pl_b = bytes from a head's q slice to its k slice (and from k to v).  dqkv, out and dout stay row-major.
+struct QkvAddr { int rs; unsigned pl_b; long col0; };
+__device__ __forceinline__ QkvAddr qkv_addr(const AttnArgs& a, int head) {
+    QkvAddr q;
+    if (a.d.qkv_headmajor) {
+        const long rows = (long)a.d.B * a.tps;
+        q.rs = HD; q.pl_b = (unsigned)((long)a.d.heads * rows * HD * 2); q.col0 = (long)head * rows * HD;
+    } else {
+        q.rs = 3 * a.C; q.pl_b = (unsigned)(2 * a.C); q.col0 = (long)head * HD;
+    }
+    return q;
+}
+__device__ __forceinline__ unsigned dma_off(const int* srel_l, int t, int lane, const QkvAddr& q) {
+    const int rel = srel_l[t * 16 + (lane >> 2)];
+    const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
+    return (unsigned)(((long)rel * q.rs + q.col0 + lslot * 8) * 2);
+}
+
 // B-operand identity fragment of k-slab `slab` (16 of the 32 contraction indices): I[k][j] = (k == j)
 __device__ __forceinline__ bf16x8 ident_frag(int slab, int j, int hi) {
     float e8[8];
@@ -127,15 +151,16 @@ __global__ __launch_bounds__(512) void win_fwd3(AttnArgs a, int bsplit) {
     }
     __syncthreads();
     unsigned offq[2], offk[2], offv[2];
+    const QkvAddr qa = qkv_addr(a, g.head);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        offq[i] = dma_off(srel_l, wave * 2 + i, lane, ld, g.head * HD);
-        offk[i] = offq[i] + 2 * C;
-        offv[i] = offq[i] + 4 * C;
+        offq[i] = dma_off(srel_l, wave * 2 + i, lane, qa);
+        offk[i] = offq[i] + qa.pl_b;
+        offv[i] = offq[i] + 2 * qa.pl_b;
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto issue = [&](int b, int buf) {
-        const bf16_t* base = a.qkv + (long)b * a.tps * ld;
+        const bf16_t* base = a.qkv + (long)b * a.tps * qa.rs;
         const unsigned d0 = lds0 + buf * BUF + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -265,28 +290,29 @@ __global__ __launch_bounds__(512) void win_dq3(AttnArgs a, int bsplit, float* nd
     const bf16x8 id0 = ident_frag(0, j, hi), id1 = ident_frag(1, j, hi);
     __syncthreads();
     unsigned offk[2], offq[2], offg[2];                       // a 256-row image = 16 one-KB pieces: two per wave and operand
+    const QkvAddr qa = qkv_addr(a, g.head);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        offk[i] = dma_off(srel_l, wave * 2 + i, lane, ld, C + g.head * HD);
-        offq[i] = dma_off(srel_l, wave * 2 + i, lane, ld, g.head * HD);
+        offq[i] = dma_off(srel_l, wave * 2 + i, lane, qa);
+        offk[i] = offq[i] + qa.pl_b;
         offg[i] = dma_off(srel_l, wave * 2 + i, lane, C, g.head * HD);
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned strip0 = lds0 + 2 * BUF + wave * 6144;
     const long lse_row = (long)g.ws * a.d.heads + g.head;       // + b * nWs * heads
     auto issue_kv = [&](int b, int buf) {
-        const bf16_t* base = a.qkv + (long)b * a.tps * ld;
+        const bf16_t* base = a.qkv + (long)b * a.tps * qa.rs;
         const unsigned d0 = lds0 + buf * BUF + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             dma16(d0 + i * 1024, base, offk[i]);
-            dma16(d0 + 16384 + i * 1024, base, offk[i] + 2 * C);
+            dma16(d0 + 16384 + i * 1024, base, offk[i] + qa.pl_b);
         }
         if (wave == 0)
             dma16(lds0 + buf * BUF + 32768, a.lse + ((long)b * a.nWs * a.d.heads + lse_row) * a.Npad, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
     };
     auto issue_strip = [&](int b) {
-        const bf16_t* bq = a.qkv + (long)b * a.tps * ld;
+        const bf16_t* bq = a.qkv + (long)b * a.tps * qa.rs;
         const bf16_t* bg = a.dout + (long)b * a.tps * C;
         const bf16_t* bo = a.out + (long)b * a.tps * C;
 #pragma unroll
@@ -411,17 +437,18 @@ __global__ __launch_bounds__(512) void win_dkv3(AttnArgs a, int bsplit, const fl
     const bf16x8 id0 = ident_frag(0, j, hi), id1 = ident_frag(1, j, hi);
     __syncthreads();
     unsigned offq[2], offg[2], offk[2];
+    const QkvAddr qa = qkv_addr(a, g.head);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        offq[i] = dma_off(srel_l, wave * 2 + i, lane, ld, g.head * HD);
+        offq[i] = dma_off(srel_l, wave * 2 + i, lane, qa);
         offg[i] = dma_off(srel_l, wave * 2 + i, lane, C, g.head * HD);
-        offk[i] = offq[i] + 2 * C;
+        offk[i] = offq[i] + qa.pl_b;
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned strip0 = lds0 + 2 * BUF + wave * 4096;
     const long lse_row = (long)g.ws * a.d.heads + g.head;
     auto issue_q = [&](int b, int buf) {
-        const bf16_t* bq = a.qkv + (long)b * a.tps * ld;
+        const bf16_t* bq = a.qkv + (long)b * a.tps * qa.rs;
         const bf16_t* bg = a.dout + (long)b * a.tps * C;
         const unsigned d0 = lds0 + buf * BUF + wave * 2048;
 #pragma unroll
@@ -434,11 +461,11 @@ __global__ __launch_bounds__(512) void win_dkv3(AttnArgs a, int bsplit, const fl
         if (wave == 1) dma16(lds0 + buf * BUF + 32768 + 1024, ndelta_in + lo, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
     };
     auto issue_strip = [&](int b) {
-        const bf16_t* bq = a.qkv + (long)b * a.tps * ld;
+        const bf16_t* bq = a.qkv + (long)b * a.tps * qa.rs;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             dma16(strip0 + i * 1024, bq, offk[i]);
-            dma16(strip0 + 2048 + i * 1024, bq, offk[i] + 2 * C);
+            dma16(strip0 + 2048 + i * 1024, bq, offk[i] + qa.pl_b);
         }
     };
     issue_q(g.b0, 0);
@@ -587,21 +614,22 @@ __global__ __launch_bounds__(512) void win_dbias3(AttnArgs a, int bsplit, const 
         for (int r = 0; r < 16; ++r) dsa[t][r] = 0.f;
     __syncthreads();
     unsigned offk[2], offs[2];
+    const QkvAddr qa = qkv_addr(a, g.head);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) offk[i] = dma_off(srel_l, wave * 2 + i, lane, ld, C + g.head * HD);
+    for (int i = 0; i < 2; ++i) offk[i] = dma_off(srel_l, wave * 2 + i, lane, qa) + qa.pl_b;
     // Q / dO strips of this query half: 4 strips x 2 pieces, wave w moves piece w of each operand
-    offs[0] = dma_off(srel_l, qh * 8 + wave, lane, ld, g.head * HD);
+    offs[0] = dma_off(srel_l, qh * 8 + wave, lane, qa);
     offs[1] = dma_off(srel_l, qh * 8 + wave, lane, C, g.head * HD);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const long lse_row = (long)g.ws * a.d.heads + g.head;
     auto issue = [&](int b, int buf) {
-        const bf16_t* bq = a.qkv + (long)b * a.tps * ld;
+        const bf16_t* bq = a.qkv + (long)b * a.tps * qa.rs;
         const bf16_t* bg = a.dout + (long)b * a.tps * C;
         const unsigned d0 = lds0 + buf * BUF;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             dma16(d0 + wave * 2048 + i * 1024, bq, offk[i]);
-            dma16(d0 + 16384 + wave * 2048 + i * 1024, bq, offk[i] + 2 * C);
+            dma16(d0 + 16384 + wave * 2048 + i * 1024, bq, offk[i] + qa.pl_b);
         }
         dma16(d0 + 32768 + wave * 1024, bq, offs[0]);
         dma16(d0 + 32768 + 8192 + wave * 1024, bg, offs[1]);

@@ -34,6 +34,8 @@ struct GemmArgs {
     int owner;            // out_mode 2 with one block per output tile: plain read-modify-write instead of atomics
     int group_n;          // > 0: tiles are walked in column groups of this many tiles (B panels of a group stay in the XCD's L2)
     int dbg;              // probe only (lav_gemm_select(5, v), wrong results): 1 = return before the epilogue, 2 = skip the k-loop, 4 = skip the epilogue's staging writes
+    int nb_rows;          // > 0: B has only this many valid rows while N was rounded up to a multiple of 8 (lav_gemm_epilogue.c_pad_writable):
+                          // B row reads and bias reads are clamped to it, the extra output columns receive unspecified values
     int nt_preact;        // store the saved-for-backward GELU' tensor with non-temporal stores (it is not read again before the backward:
                           // keeping it out of L2 / MALL is worth 0.6 ms per cfg2 step; LAV_NT_STORES=0 turns it off)
 };
@@ -211,6 +213,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
     float (&lng)[8] = st.lng;
     float (&lnb)[8] = st.lnb;
     const int ncols = min(8, g.N - gcol);              // <=0: chunk outside
+    // bf16 output addressing: element (row, gcol + x) at C + row * out_rs + out_c0 + x.  Head-major (lav_gemm_epilogue.hm_*): the 8 columns of a
+    // chunk lie inside one head (hm_head_dim % 8 == 0), whose block is [hm_rows][hm_head_dim]
+    long out_rs = g.ldc, out_c0 = gcol;
+    if (e.hm_heads > 0) {
+        const int hw = e.hm_heads * e.hm_head_dim, pl = gcol / hw, hc = gcol - pl * hw;
+        out_rs = e.hm_head_dim;
+        out_c0 = ((long)(pl * e.hm_heads + hc / e.hm_head_dim) * e.hm_rows) * e.hm_head_dim + hc % e.hm_head_dim;
+    }
     const bool has_resln = (GEN || (F & EF_O32)) && (F & EF_RES) && e.residual && e.residual_f32 && e.res_ln_mean;
     if (phase & 1) {
 #pragma unroll
@@ -218,7 +228,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
         if (has_bias && ncols > 0) {
 #pragma unroll
             for (int x = 0; x < 8; ++x)
-                if (x < ncols) bias[x] = e.bias[gcol + x];
+                if (x < ncols && (g.nb_rows == 0 || gcol + x < g.nb_rows)) bias[x] = e.bias[gcol + x];
         }
         // LayerNorm of the residual rows (res_ln_*): this thread's 8 columns of gamma / beta, once
         if (has_resln && ncols > 0) {
@@ -374,7 +384,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
                        + row * BN + cc * 8;
             *(float4*)p = *(float4*)&v[0]; *(float4*)(p + 4) = *(float4*)&v[4];
         } else if (GEN ? e.out_mode == 0 : !(F & EF_O32)) {
-            bf16_t* p = (bf16_t*)g.C + (long)grow * g.ldc + gcol;
+            bf16_t* p = (bf16_t*)g.C + (long)grow * out_rs + out_c0;      // row-major (ldc, gcol) or head-major (hm_head_dim, block base)
             if (full) *(uint4*)p = pack8(v);
             else for (int x = 0; x < ncols; ++x) p[x] = f2bf(v[x]);
         } else if (!GEN || e.out_mode == 1) {
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs g) {
         const int k0 = kbeg + kt * BKT;
         if (AKC) big_glds<true, 4>(st, g.A, g.lda, m0, g.M, k0, wave, lane);          // 256 rows x 128 B = 32 instr
         else huge_glds_strided(st, g.A, g.lda, m0, g.M, k0, wave, lane);              // [64 k][256 m], 32 instr
-        big_glds<BKC, 2>(st + 32768, g.B, g.ldb, n0, g.N, k0, wave, lane);            // 16 KB = 16 instr
+        big_glds<BKC, 2>(st + 32768, g.B, g.ldb, n0, g.nb_rows ? g.nb_rows : g.N, k0, wave, lane);   // 16 KB = 16 instr
     };
     if (nk > 0) issue(0);
     if (nk > 1) {
@@ -1045,197 +1055,8 @@ __global__ __launch_bounds__(512) void gemm_h192_kernel(GemmArgs g) { gemm_huge_
 // stream), so it is not kept.
 template <bool AKC, bool BKC, unsigned F>
 __global__ __launch_bounds__(640) void gemm_h192l_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 8, 6, 256, 2>(g); }
-// 192 x 128 tiles on FOUR waves (2 x 2 of 96 x 64, the h192 wave tile) with 2 x 40 KB of stages: TWO workgroups fit a CU (LDS 2 x 80 KB,
-// 162 VGPRs, 2 waves per SIMD), so one workgroup's epilogue (HBM-bound, matrix pipe idle) runs under the other's k-loop.  Round-3
-// experiment, NOT selected by default (LAV_GEMM_Q=1 forces it, 9 = long-K narrow outputs only; tools/q_probe.py): bit-identical results;
-// isolated it wins 4-5 % on 45120 x 768 x {2304, 3072} and loses 0-34 % everywhere else (the tile moves 1.63x the operand bytes per flop
-// through L2 -> LDS and reads 10 fragments per 24 MFMAs instead of 12 per 32); the step goes 77.9 -> 80.5 ms with it everywhere and
-// stays where it is with it on the two shapes it wins.  Co-resident workgroups do hide the epilogue; the smaller tile costs more.
-#define Q_LDS 81920
-template <bool AKC, bool BKC, unsigned F>
-__global__ __launch_bounds__(256, 2) void gemm_q_kernel(GemmArgs g) { gemm_huge_body<AKC, BKC, F, 4, 6, 128>(g); }
-
 // ------------------------------------------------------------------------------------------------------
-// Round 4: PERSISTENT form of the 256 (192) x 256 K-contiguous kernel with a specialised epilogue (the forward and input-gradient
-// GEMMs of the step).  One workgroup per CU walks the tile sequence w = blockIdx.x, + gridDim.x, ... (the same XCD-contiguous order as
-// the one-tile-per-workgroup kernels: gridDim.x is a multiple of 8, so a workgroup's tiles stay on its XCD's run).
-// For the operand DMA a tile boundary is just another k-step: the LAST k-iteration of a tile issues the first operand stage of the
-// NEXT tile into the stage that iteration does not read, so the ~2 us HBM / L2 round trip of a tile's prologue (measured: 18 us of a
-// 237 us launch on 45120 x 3072 x 768, 8.3 tiles per CU) lands under the last k-tile's MFMAs, and the epilogue runs without any
-// DMA wait -- its global stores are never waited for either (the next explicit vmcnt(0) is at the end of the next tile's first
-// k-iteration).  The stage holding the next tile's operands alternates when a tile has an odd number of k-steps (`sp`), and the
-// epilogue's wave-private staging slices (32-row chunks: 8 x 32 rows x 68 floats) live in whatever LDS that stage leaves free;
-// they may overlap the OTHER stage, which is only refilled after barrier (A) of the next tile, when every wave has left its epilogue.
-// LW > 0: loader waves issue every DMA (the 192-row tile, see gemm_h192l_kernel) and follow the same barrier sequence; the compute
-// waves then never execute a vmcnt wait at all.
-// Results are bit-identical to the one-tile kernels (same k order, same epilogue arithmetic).
-// ------------------------------------------------------------------------------------------------------
-#define PERS_LDS 139776                                   // stage 1 resident + seven slices below it + the eighth behind it: 131072 + 8704
-template <unsigned F, int RF, int LW>
-__device__ __forceinline__ void gemm_pers_body(const GemmArgs& g) {
-    static_assert(F != EF_ALL && F != EF_TNFLUSH, "persistent kernel: specialised epilogues only");
-    constexpr int NW = 8, WN = 4, NJ = 4;
-    constexpr int BMT = 2 * RF * 16;                      // tile rows
-    constexpr int NI = LW > 0 ? LW : NW;                  // waves that issue the operand DMA
-    constexpr int PA = BMT / 8 / NI, PB = 256 / 8 / NI;   // 1-KB pieces per issuing wave per A / B tile
-    constexpr int BOFF = 32768, STAGE = HUGE_STAGE;
-    constexpr int WS = 68, CF = 2;                        // epilogue chunk: 32 rows x 64 columns per wave, row stride 68 floats
-    constexpr int SLICE = CF * 16 * WS * 4;               // 8704 bytes
-    static_assert(7 * SLICE <= STAGE && 2 * STAGE + SLICE <= PERS_LDS && STAGE + NW * SLICE <= PERS_LDS, "epilogue slices vs stages");
-    static_assert(RF % CF == 0, "row fragments per epilogue chunk");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = g.N / 256, tiles_m = (g.M + BMT - 1) / BMT;
-    const int nwg = tiles_m * tiles_n;
-    const int G = gridDim.x;
-    const int nk = g.K / BKT;
-    auto tile_of = [&](int w, int& m0, int& n0) {
-        int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
-        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        int tm = bid / tiles_n, tn = bid % tiles_n;
-        if (g.group_n > 0 && g.group_n < tiles_n) {
-            const int per = tiles_m * g.group_n, cg = bid / per, rem = bid - cg * per;
-            const int gw = min(g.group_n, tiles_n - cg * g.group_n);          // last group may be narrower
-            tm = rem / gw; tn = cg * g.group_n + rem % gw;
-        }
-        m0 = tm * BMT; n0 = tn * 256;
-    };
-    // operand DMA of the issuing waves: a lane's source rows are fixed over a tile's k-loop (A through the optional pair-expansion row map)
-    const bool issuer = LW > 0 ? wave >= NW : true;
-    const int li = LW > 0 ? wave - NW : wave;
-    const int sw = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
-    const bf16_t* ar[PA];
-    const bf16_t* br[PB];
-    auto set_src = [&](int m0, int n0) {
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            int r = min(m0 + (li * PA + i) * 8 + (lane >> 3), g.M - 1);
-            if (g.e.a_rowmap) r = g.e.a_rowmap[r];
-            ar[i] = g.A + (long)r * g.lda + sw;
-        }
-#pragma unroll
-        for (int i = 0; i < PB; ++i) br[i] = g.B + (long)min(n0 + (li * PB + i) * 8 + (lane >> 3), g.N - 1) * g.ldb + sw;
-    };
-    auto issue = [&](int stage, int kt) {
-        char* st = smem + stage * STAGE;
-        const int k0 = kt * BKT;
-#pragma unroll
-        for (int i = 0; i < PA; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ar[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(st + (li * PA + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < PB; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(br[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(st + BOFF + (li * PB + i) * 1024), 16, 0, 0);
-    };
-    int w = blockIdx.x, m0, n0;
-    int sp = 0;                                             // stage that holds k-tile 0 of the current tile
-    tile_of(w, m0, n0);
-    if (issuer) { set_src(m0, n0); if (nk > 0) issue(0, 0); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bool skip_k = (g.dbg & 2) != 0;                   // probe: no k-loop (the next tile's first stage is still issued, at the tile boundary)
-
-    if constexpr (LW > 0) {
-        if (wave >= NW) {                                   // loader waves: DMA only, same barrier sequence as the compute waves
-            for (;;) {
-                const int wnext = w + G;
-                const bool more = wnext < nwg;
-                __builtin_amdgcn_s_barrier();               // (A)
-                for (int kt = 0; kt < (skip_k ? 0 : nk); ++kt) {
-                    const int st = (sp + kt) & 1;
-                    if (kt + 1 < nk) issue(st ^ 1, kt + 1);
-                    else if (more) { tile_of(wnext, m0, n0); set_src(m0, n0); issue(st ^ 1, 0); }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
-                if (skip_k) {
-                    if (more && nk > 0) { tile_of(wnext, m0, n0); set_src(m0, n0); issue((sp + nk) & 1, 0); }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
-                if (!more) return;
-                w = wnext; sp = (sp + nk) & 1;
-            }
-        }
-    }
-    const int wm = wave / WN, wn = wave % WN;
-    for (;;) {
-        f32x4 acc[RF][NJ];
-#pragma unroll
-        for (int i = 0; i < RF; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int wnext = w + G;
-        const bool more = wnext < nwg;
-        int m1 = 0, n1 = 0;
-        if (more) tile_of(wnext, m1, n1);
-        __builtin_amdgcn_s_barrier();                       // (A): every wave has left the previous epilogue (its slices may overlap the stage refilled next)
-        for (int kt = 0; kt < (skip_k ? 0 : nk); ++kt) {
-            const int st = (sp + kt) & 1;
-            const char* la = smem + st * STAGE;
-            const char* lb = la + BOFF;
-            if constexpr (LW == 0) {
-                if (kt + 1 < nk) issue(st ^ 1, kt + 1);
-                else if (more) { set_src(m1, n1); issue(st ^ 1, 0); }      // tile boundary: the next tile's first stage, under this k-tile's MFMAs
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[RF], fb[NJ];
-#pragma unroll
-                for (int i = 0; i < RF; ++i) fa[i] = frag_read<true>(la, wm * RF + i, ks, lane);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) fb[j] = frag_read<true>(lb, wn * NJ + j, ks, lane);
-#pragma unroll
-                for (int i = 0; i < RF; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            }
-            if constexpr (LW == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        const int X = (sp + nk) & 1;                        // stage that now holds the next tile's k-tile 0: off limits to the epilogue
-        if (skip_k) {
-            if constexpr (LW == 0) { if (more && nk > 0) { set_src(m1, n1); issue(X, 0); } asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            __builtin_amdgcn_s_barrier();
-        }
-        if (!(g.dbg & 1)) {
-            // wave-private slice: behind stage 0 when that is the resident stage, else seven slices in stage 0 and the eighth behind stage 1
-            const int soff = __builtin_amdgcn_readfirstlane(X == 0 ? STAGE + wave * SLICE : (wave < 7 ? wave * SLICE : 2 * STAGE));
-            float* clw = (float*)(smem + soff);
-            const int mc = m0 + wm * (RF * 16), nc = n0 + wn * 64;
-            EpiState es;
-#pragma unroll
-            for (int h = 0; h < RF / CF; ++h) {               // unrolled: acc[] must be indexed with compile-time constants
-                if (!(g.dbg & 4)) {
-#pragma unroll
-                    for (int i = 0; i < CF; ++i)
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                clw[(i * 16 + (lane >> 4) * 4 + r) * WS + j * 16 + (lane & 15)] = acc[h * CF + i][j][r];
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the slice is only read by this wave
-                __builtin_amdgcn_wave_barrier();
-                gemm_epilogue<CF * 16, 64, F, 8, WS>(g, clw, mc + h * (CF * 16), nc, 0, es, (h == 0 ? 1 : 0) | (h == RF / CF - 1 ? 2 : 0));
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (!more) return;
-        w = wnext; m0 = m1; n0 = n1; sp = X;
-    }
-}
-template <unsigned F>
-__global__ __launch_bounds__(512) void gemm_p256_kernel(GemmArgs g) { gemm_pers_body<F, 8, 0>(g); }
-template <unsigned F>
-__global__ __launch_bounds__(640) void gemm_p192l_kernel(GemmArgs g) { gemm_pers_body<F, 6, 2>(g); }
-template <unsigned F>
-__global__ __launch_bounds__(512) void gemm_p192_kernel(GemmArgs g) { gemm_pers_body<F, 6, 0>(g); }      // fp32-output epilogue: does not fit the loader variant's 168 registers
-
-// ------------------------------------------------------------------------------------------------------
-// Ping-pong 256x256x32 kernels.  8 waves in two groups of four -- group g = wave >> 2 owns rows [128 g, 128 g + 128) of
+// Ping-pong 256x256x32 weight-gradient kernel.  8 waves in two groups of four -- group g = wave >> 2 owns rows [128 g, 128 g + 128) of
 // the tile, wave & 3 its 64-column strip -- so every SIMD hosts ONE wave of each group (waves w and w + 4 land on the
 // same SIMD).  The groups run the same READ(t) / COMPUTE(t) sequence ONE barrier apart: while a group's waves issue
 // their 16 v_mfma_f32_32x32x16_bf16 of k-tile t (pure register work, 512 cycles), the partner waves on the same SIMDs
@@ -1245,38 +1066,15 @@ __global__ __launch_bounds__(512) void gemm_p192_kernel(GemmArgs g) { gemm_pers_
 // K-contiguous layout (measured: the 2-phase TN kernel is LDS-ISSUE bound at ~600 TFLOP/s, half the NT rate).
 // k-tiles of 32 in a ring of four 32 KB stages: a stage is refilled two barriers after its last read and has ~4 steps
 // to land, waited for with a COUNTED vmcnt.
-//   NT stage: [256 rows][64 B] per operand, 16-byte slot s of row r stored at s ^ ((r >> 2) & 3) (the sixteen rows one
-//             ds_read_b128 lane group touches fall on sixteen distinct bank slots).
-//   TN stage: [32 k][256 n] per operand, 512-byte k-rows, 32-byte chunk c of row k stored at c ^ skey(k) (as above).
-// Measured (tools/gemm_pp_ablate.py): per 16-MFMA step 364 ns with MFMAs + fragment reads only, ~550 ns with the NT
-// refills (64-byte row pieces: 27 GB/s per CU) -- the per-CU L2 -> LDS stream, not the matrix pipe or the LDS, is what
-// paces a 256x256 tile, which is why the NT layout stays on the 2-phase kernel above (128-byte row pieces, 34 GB/s per CU).
+//   stage: [32 k][256 n] per operand, 512-byte k-rows, 32-byte chunk c of row k stored at c ^ skey(k).
+// The same schedule on the K-contiguous (forward / input-gradient) layout was built in round 2 and only tied the 2-phase
+// 256 x 256 kernel -- its 32-wide k-tiles are 64-byte row pieces, 50 instead of 75 GB/s per CU out of L2
+// (profiles/r02_gemm_feed_ubench.md) -- and was removed in round 4 (profiles/r04_gemm_experiments.md).
 // ------------------------------------------------------------------------------------------------------
 #define PP_BK 32
 #define PP_STAGE 32768
 #define PP_NS 4
 #define PP_LDS HUGE_LDS
-
-template <bool TN>
-__device__ __forceinline__ void pp_issue(char* st, const GemmArgs& g, int m0, int n0, int k0, int wave, int lane) {
-    if (TN) {
-        huge_glds_strided<2>(st, g.A, g.lda, m0, g.M, k0, wave, lane);            // [32 k][256 m]: 16 pieces, 2 per wave
-        huge_glds_strided<2>(st + 16384, g.B, g.ldb, n0, g.N, k0, wave, lane);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int t = wave * 2 + i;                        // 1-KB piece = 16 rows x 64 B
-        const int rt = t * 16 + (lane >> 2);
-        const int slot = (lane & 3) ^ ((lane >> 4) & 3);   // logical slot that lands on physical slot lane & 3 of row rt
-        const bf16_t* sa = g.A + (long)min(m0 + rt, g.M - 1) * g.lda + k0 + slot * 8;
-        const bf16_t* sb = g.B + (long)min(n0 + rt, g.N - 1) * g.ldb + k0 + slot * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
-                                         (__attribute__((address_space(3))) void*)(st + t * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
-                                         (__attribute__((address_space(3))) void*)(st + 16384 + t * 1024), 16, 0, 0);
-    }
-}
 
 // 32x32x16 operand fragment (32 rows/cols x 16 k) of a contraction-strided tile [k][256], 512-byte k-rows: byte offset of
 // this lane's first transposing read inside the tile (k-rows k .. k+3); the second read (k+4 .. k+7) is 2048 bytes further
@@ -1305,29 +1103,6 @@ __device__ __forceinline__ bf16x8 join_frag(s16x4 lo, s16x4 hi) {
     return u.v;
 }
 
-// one of the four 1-KB pieces a wave contributes to a stage: p = 0, 1 operand A, p = 2, 3 operand B
-template <bool TN>
-__device__ __forceinline__ void pp_issue_piece(char* st, const GemmArgs& g, int m0, int n0, int k0, int wave, int lane, int p) {
-    const int t = wave * 2 + (p & 1);
-    const bool isb = p >= 2;
-    const bf16_t* P = isb ? g.B : g.A;
-    const long ld = isb ? g.ldb : g.lda;
-    const int o0 = isb ? n0 : m0, O = isb ? g.N : g.M;
-    const bf16_t* src;
-    if (TN) {
-        const int krow = t * 2 + (lane >> 5);
-        const int ch = ((lane & 31) >> 1) ^ skey(krow);
-        const int col = min(o0 + ch * 16 + (lane & 1) * 8, ((O + 7) & ~7) - 8);
-        src = P + (long)(k0 + krow) * ld + col;
-    } else {
-        const int rt = t * 16 + (lane >> 2);
-        const int slot = (lane & 3) ^ ((lane >> 4) & 3);
-        src = P + (long)min(o0 + rt, O - 1) * ld + k0 + slot * 8;
-    }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(st + (isb ? 16384 : 0) + t * 1024), 16, 0, 0);
-}
-
 // TN refill piece as inline asm, scalar base + per-lane 32-bit offset (no per-piece VALU, 4 offset registers per wave in
 // total).  Why asm: with the builtin hipcc knows an LDS-DMA is outstanding and drains it (s_waitcnt vmcnt(0)) in front of
 // every ds_read_b64_tr_b16 -- the transposing read "may alias" -- which serialises the refill pipeline.  Hidden from its
@@ -1346,6 +1121,7 @@ __device__ __forceinline__ void pp_wait_tiles(int rem) {   // s_waitcnt vmcnt(4 
 
 template <bool TN, unsigned F, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
+    static_assert(TN && F == EF_TNFLUSH && DBG == 0, "ping-pong kernel: weight-gradient layout only (the K-contiguous form was removed in round 4)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1385,11 +1161,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             for (int j = 0; j < 2; ++j) tob[j][s2] = 16384 + pp_frag_strided_off(wn * 2 + j, s2, lane);
         }
     }
-    // NT: per-lane LDS offsets of the fragment reads: row (lane & 31) of a 32-row block, logical slot 2 s + (lane >> 5)
-    int lo[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) lo[s2] = (lane & 31) * 64 + ((((2 * s2 + (lane >> 5)) ^ ((lane >> 2) & 3))) << 4);
-    const int abase = grp * 128 * 64, bbase = 16384 + wn * 64 * 64;
     // TN: bias gradient = row sums of A^T (= column sums of dy), by the wn == 0 waves of the n0 == 0 blocks, on the VALU
     // from the A fragments they hold anyway (a ones-fragment MFMA would need 64 more accumulator registers per wave)
     const bool do_rowsum = TN && g.e.rowsum_a != nullptr && n0 == 0 && wn == 0;
@@ -1418,8 +1189,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((tdst % PP_NS) * PP_STAGE + (isb ? 16384 : 0) + tp * 1024));
             const bf16_t* base = (isb ? g.B : g.A) + (long)(kbeg + tsrc * PP_BK) * (isb ? g.ldb : g.lda);
             pp_dma_saddr(dst, base, voff[p]);     // (non-temporal operand loads here were measured +0.9 ms per step: the dx GEMM of the main stream shares dy through the caches)
-        } else {
-            pp_issue_piece<false>(smem + (tdst % PP_NS) * PP_STAGE, g, m0, n0, kbeg + tsrc * PP_BK, wave, lane, p);
         }
     };
     auto issue = [&](int t) {
@@ -1476,14 +1245,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
                         fa[i][s2] = u.v;
                     }
                 }
-            }
-        } else {
-#pragma unroll
-            for (int s2 = 0; s2 < ((DBG & 2) ? (t == 0 ? 2 : 0) : 2); ++s2) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j][s2] = *(const bf16x8*)(st + bbase + j * 2048 + lo[s2]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i][s2] = *(const bf16x8*)(st + abase + i * 2048 + lo[s2]);
             }
         }
     };
@@ -1588,26 +1349,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             gemm_epilogue<BIG_BM, 512, F>(g, cl, m0, n0 + h * 128, split);
             __syncthreads();
         }
-        return;
-    } else {
-        // each wave stages its 128 x 64 block through a private LDS slice in two 64-row halves
-        constexpr int WS = 68;
-        float* clw = (float*)smem + wave * (64 * WS);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        clw[(i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WS + j * 32 + (lane & 31)] = acc[h * 2 + i2][j][r];
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            gemm_epilogue<64, 64, F, 8, WS>(g, clw, m0 + grp * 128 + h * 64, n0 + wn * 64, split);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-        }
     }
 }
 
@@ -1687,45 +1428,22 @@ static float* splitk_workspace(void* stream, size_t bytes) {
     return e->ptr;
 }
 
-// test hook: route everything through the 128x128 kernel (set by LAV_GEMM_SMALL=1)
-static const bool lav_gemm_force_small = getenv("LAV_GEMM_SMALL") != nullptr;
-static const bool lav_gemm_no_huge = getenv("LAV_GEMM_NO_HUGE") != nullptr;
 static const int lav_gemm_tn_kind = getenv("LAV_GEMM_TN_KIND") ? atoi(getenv("LAV_GEMM_TN_KIND")) : -1;   // probe hook: 0 = 128x128 only, 1 = at most 256x128, default = largest tile that fits
-static const bool lav_gemm_atomic_flush = getenv("LAV_GEMM_ATOMIC_FLUSH") != nullptr;   // test hook: the old atomic split-K flush
-static bool lav_gemm_pp = getenv("LAV_GEMM_PP") ? atoi(getenv("LAV_GEMM_PP")) != 0 : false;   // ping-pong 256x256x32 kernel
 static bool lav_gemm_pp_tn = getenv("LAV_GEMM_PP_TN") ? atoi(getenv("LAV_GEMM_PP_TN")) != 0 : true;   // ping-pong kernel for the 256x256 weight-gradient tiles
 // tile walk of the 256x256 K-contiguous kernel: column groups of 4 tiles when the output is >= 8 tiles wide (an XCD's 32 resident
 // tiles then form an 8 x 4 block: 12 operand panels in its L2 instead of 15 for 2.7 rows x 12 columns; measured +8-12 % on the
 // 45120 x 3072 x 768 GEMMs and on 8192^3, nothing on narrower outputs).  LAV_GEMM_GROUP_N=0 restores n-fastest, other values force G.
 static int lav_gemm_group_n = getenv("LAV_GEMM_GROUP_N") ? atoi(getenv("LAV_GEMM_GROUP_N")) : -1;
 static int lav_gemm_h192 = getenv("LAV_GEMM_H192") ? atoi(getenv("LAV_GEMM_H192")) : 1;          // 192-row tiles for outputs that under-fill the last round of 256-row tiles
-static int lav_gemm_h192l = getenv("LAV_GEMM_H192L") ? atoi(getenv("LAV_GEMM_H192L")) : 1;                         // 192-row tiles: two loader waves issue the operand DMA (0 = off, 2 = probe: on every 256-column shape)
-static int lav_gemm_q = getenv("LAV_GEMM_Q") ? atoi(getenv("LAV_GEMM_Q")) : 0;                                     // 192x128 four-wave tiles, two workgroups per CU
-static int lav_gemm_pers = getenv("LAV_GEMM_PERS") ? atoi(getenv("LAV_GEMM_PERS")) : 0;                            // persistent tile-walking kernels (gemm_p256 / gemm_p192l) for the specialised K-contiguous launches
-static int lav_num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount;
-        else { (void)hipGetLastError(); n = 256; }
-        n -= n % 8;                                          // a multiple of the XCD count: a workgroup's tiles stay on one XCD's run
-        if (n < 8) n = 8;
-    }
-    return n;
-}
+static int lav_gemm_h192l = getenv("LAV_GEMM_H192L") ? atoi(getenv("LAV_GEMM_H192L")) : 1;                         // 192-row tiles: two loader waves issue the operand DMA (0 = off)
 static int lav_gemm_dbg = getenv("LAV_GEMM_DBG") ? atoi(getenv("LAV_GEMM_DBG")) : 0;                               // probe hook: GemmArgs.dbg of the 256x256 kernel
-static int lav_gemm_pp_dbg = 0;                            // ablation builds of the ping-pong kernel (probe only, wrong results): 1 no refills, 2 no fragment reads, 4 no MFMAs
 extern "C" int lav_gemm_select(int which, int value) {    // probe hook (within-process A/B): which 0 = ping-pong kernel on/off; returns the old value
     int old = -1;
-    if (which == 0) { old = lav_gemm_pp; lav_gemm_pp = value != 0; }
-    if (which == 1) { old = lav_gemm_pp_dbg; lav_gemm_pp_dbg = value; }
     if (which == 2) { old = lav_gemm_pp_tn; lav_gemm_pp_tn = value != 0; }
     if (which == 5) { old = lav_gemm_dbg; lav_gemm_dbg = value; }
     if (which == 6) { old = lav_gemm_group_n; lav_gemm_group_n = value; }
     if (which == 7) { old = lav_gemm_h192; lav_gemm_h192 = value; }
-    if (which == 8) { old = lav_gemm_q; lav_gemm_q = value; }
     if (which == 9) { old = lav_gemm_h192l; lav_gemm_h192l = value; }
-    if (which == 10) { old = lav_gemm_pers; lav_gemm_pers = value; }
     return old;
 }
 
@@ -1752,6 +1470,9 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     LAV_REQUIRE(splits == 1 || g.e.out_mode == 2 || (g.e.out_mode == 0 && layout != 2 && no_epilogue && (N % 8) == 0),
                 "lav_gemm_bf16: split-K needs out_mode=2 (fp32 accumulate), or a bf16 output without epilogue and N %% 8 == 0");
     LAV_REQUIRE(g.e.out_mode != 0 || (ldc % 8) == 0, "lav_gemm_bf16: bf16 output needs ldc %% 8 == 0");
+    LAV_REQUIRE(g.e.hm_heads <= 0 || (g.e.out_mode == 0 && layout != 2 && splits == 1 && g.e.hm_head_dim > 0 && (g.e.hm_head_dim % 8) == 0 &&
+                                      (N % (g.e.hm_heads * g.e.hm_head_dim)) == 0 && g.e.hm_rows >= M),
+                "lav_gemm_bf16: head-major store needs a bf16 output, layout 0 / 1, no split-K, hm_head_dim %% 8 == 0, N %% (hm_heads * hm_head_dim) == 0 and hm_rows >= M");
     LAV_REQUIRE(g.e.out_mode == 0 || (ldc % 4) == 0, "lav_gemm_bf16: fp32 output needs ldc %% 4 == 0");
     int kps = ((K + splits - 1) / splits + BKT - 1) / BKT * BKT;
     g.k_per_split = kps;
@@ -1769,7 +1490,16 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         (void)hipGetLastError();
         attr_set = true;
     }
-    const bool big = layout != 2 && splits == 1 && (K % BKT) == 0 && M >= 2048 && !lav_gemm_force_small;
+    // ragged N whose padding columns the caller lets us overwrite (the 30522-wide vocabulary projection into its 30528-wide logits
+    // buffer): run as N rounded up to 8 so that the 16-byte-chunk epilogues apply (the generic one was 566 vs 256 us for the vendor
+    // library on 5120 x 30522 x 768); B rows and bias entries past the real N are never read
+    if (g.e.c_pad_writable && (N % 8) != 0 && layout == 0 && splits == 1 && (K % BKT) == 0 && M >= 2048 && g.e.out_mode == 0 &&
+        ldc >= (long)((N + 7) / 8 * 8) && !g.e.colsum && !g.e.preact && !g.e.gelu_in && !g.e.residual && !g.e.a_rowmap) {
+        g.nb_rows = N;
+        N = (N + 7) / 8 * 8;
+        g.N = N;
+    }
+    const bool big = layout != 2 && splits == 1 && (K % BKT) == 0 && M >= 2048;
     // epilogue feature mask of this call -> smallest instantiated superset (EF_ALL = the generic code)
     unsigned fm = 0;
     if (g.e.bias) fm |= EF_BIAS;
@@ -1786,8 +1516,8 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
                        S_BDR = EF_BIAS | EF_DROP | EF_RSCALE | EF_RES, S_BDRO = S_BDR | EF_O32;
     const unsigned fsel = !(fm & ~S_B) ? S_B : !(fm & ~S_BG) ? S_BG : !(fm & ~S_GC) ? S_GC : !(fm & ~S_BDR) ? S_BDR :
                           ((fm & EF_O32) && !(fm & ~S_BDRO)) ? S_BDRO : EF_ALL;
-    constexpr int lav_threads_gemm_huge_kernel = 512, lav_threads_gemm_big_kernel = 512, lav_threads_gemm_h192_kernel = 512, lav_threads_gemm_q_kernel = 256, lav_threads_gemm_h192l_kernel = 640;
-    (void)lav_threads_gemm_huge_kernel; (void)lav_threads_gemm_big_kernel; (void)lav_threads_gemm_h192_kernel; (void)lav_threads_gemm_q_kernel; (void)lav_threads_gemm_h192l_kernel;
+    constexpr int lav_threads_gemm_huge_kernel = 512, lav_threads_gemm_big_kernel = 512, lav_threads_gemm_h192_kernel = 512, lav_threads_gemm_h192l_kernel = 640;
+    (void)lav_threads_gemm_huge_kernel; (void)lav_threads_gemm_big_kernel; (void)lav_threads_gemm_h192_kernel; (void)lav_threads_gemm_h192l_kernel;
 #define LAV_LAUNCH_ONE(KERN, AKC_, BKC_, F_, GRID, LDS)                                                                   \
     do {                                                                                                                  \
         static bool attr_done = false;                                                                                    \
@@ -1812,54 +1542,17 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         else if (fsel == S_BDRO) LAV_LAUNCH_BY_LAYOUT(KERN, S_BDRO, GRID, LDS);                                           \
         else LAV_LAUNCH_BY_LAYOUT(KERN, EF_ALL, GRID, LDS);                                                               \
     } while (0)
-#define LAV_PP_ONE(F_, GRID)                                                                                              \
-    do {                                                                                                                  \
-        static bool attr_done = false;                                                                                    \
-        if (!attr_done) {                                                                                                 \
-            hipFuncSetAttribute((const void*)gemm_pp_kernel<false, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);     \
-            (void)hipGetLastError();                                                                                      \
-            attr_done = true;                                                                                             \
-        }                                                                                                                 \
-        hipLaunchKernelGGL((gemm_pp_kernel<false, F_>), GRID, dim3(512), PP_LDS, s, g);                                          \
-    } while (0)
-#define LAV_LAUNCH_PP(GRID)                                                                                               \
-    do {                                                                                                                  \
-        if (fsel == S_B) LAV_PP_ONE(S_B, GRID);                                                                           \
-        else if (fsel == S_BG) LAV_PP_ONE(S_BG, GRID);                                                                    \
-        else if (fsel == S_GC) LAV_PP_ONE(S_GC, GRID);                                                                    \
-        else if (fsel == S_BDR) LAV_PP_ONE(S_BDR, GRID);                                                                  \
-        else LAV_PP_ONE(S_BDRO, GRID);                                                                                    \
-    } while (0)
-#define LAV_PERS_ONE(KERN, THREADS, F_, TILES)                                                                            \
-    do {                                                                                                                  \
-        static bool attr_done = false;                                                                                    \
-        if (!attr_done) {                                                                                                 \
-            hipFuncSetAttribute((const void*)KERN<F_>, hipFuncAttributeMaxDynamicSharedMemorySize, PERS_LDS);             \
-            (void)hipGetLastError();                                                                                      \
-            attr_done = true;                                                                                             \
-        }                                                                                                                 \
-        const long ncu_ = lav_num_cus();                                                                                  \
-        hipLaunchKernelGGL((KERN<F_>), dim3((unsigned)((TILES) < ncu_ ? (TILES) : ncu_)), dim3(THREADS), PERS_LDS, s, g); \
-    } while (0)
-#define LAV_LAUNCH_PERS(KERN, THREADS, TILES)                                                                             \
-    do {                                                                                                                  \
-        if (fsel == S_B) LAV_PERS_ONE(KERN, THREADS, S_B, TILES);                                                         \
-        else if (fsel == S_BG) LAV_PERS_ONE(KERN, THREADS, S_BG, TILES);                                                  \
-        else if (fsel == S_GC) LAV_PERS_ONE(KERN, THREADS, S_GC, TILES);                                                  \
-        else if (fsel == S_BDR) LAV_PERS_ONE(KERN, THREADS, S_BDR, TILES);                                                \
-        else LAV_PERS_ONE(KERN, THREADS, S_BDRO, TILES);                                                                  \
-    } while (0)
     // pick the tile by estimated machine fill: tiles / (rounds * resident slots), weighted by the tile's own efficiency
     auto fill = [](long tiles, long slots, double w) { return w * (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
     const long t_small = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const long t_big = (long)((M + BIG_BM - 1) / BIG_BM) * ((N + BN - 1) / BN);
     const long t_huge = (long)((M + BIG_BM - 1) / BIG_BM) * (N / 256);
-    static const double w_big = getenv("LAV_GEMM_BIG_W") ? atof(getenv("LAV_GEMM_BIG_W")) : 0.80;    // probe hook; 0.80 measured best once the dW stream fills partial rounds (0.88 before)
+    constexpr double w_big = 0.80;                            // measured best once the dW stream fills partial rounds (0.88 before)
     const double f_small = fill(t_small, 512, 0.80), f_big = fill(t_big, 256, w_big);
-    const double f_huge = (N % 256) == 0 ? fill(t_huge, 256, 1.0) : 0.0;
+    const double f_huge = ((N % 256) == 0 && !g.nb_rows) ? fill(t_huge, 256, 1.0) : 0.0;
     // 192-row tiles where they fill the machine better (narrow outputs: N = 768 at M = 45120 is 2.07 rounds of 256-row tiles)
     const long t_h192 = (long)((M + 191) / 192) * (N / 256);
-    const double f_h192 = ((N % 256) == 0 && fsel != EF_ALL && lav_gemm_h192) ? fill(t_h192, 256, 0.97) : 0.0;
+    const double f_h192 = ((N % 256) == 0 && fsel != EF_ALL && lav_gemm_h192 && !g.nb_rows) ? fill(t_h192, 256, 0.97) : 0.0;
     if (g.e.a_rowmap) {                                      // pair-expanded A rows: the 256 x 256 kernel reads them through the map
         LAV_REQUIRE(layout == 0 && splits == 1 && (N % 256) == 0 && (K % BKT) == 0,
                     "lav_gemm_bf16: a_rowmap needs layout 0, splits 1, N %% 256 == 0 and K %% 64 == 0 (got layout %d, N %d, K %d)", layout, N, K);
@@ -1867,88 +1560,31 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         const int tn_ = N / 256;
         g.group_n = lav_gemm_group_n >= 0 ? lav_gemm_group_n : (tn_ >= 8 && tn_ % 4 == 0 ? 4 : 0);
         dim3 hgrid((unsigned)t_huge);
-        g.dbg = lav_gemm_dbg;
-        if (lav_gemm_pers && fsel != EF_ALL) LAV_LAUNCH_PERS(gemm_p256_kernel, 512, t_huge);
-        else LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
+        LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
         return lav_check_launch("lav_gemm_bf16");
     }
-    if (big && lav_gemm_h192l == 2 && layout == 0 && fsel != EF_ALL && (N % 256) == 0 && !g.e.a_rowmap) {     // probe: loader-wave tiles everywhere
-        g.k_per_split = K;
-        g.dbg = lav_gemm_dbg;
-        const int tn_ = N / 256;
-        g.group_n = lav_gemm_group_n >= 0 ? lav_gemm_group_n : (tn_ >= 8 && tn_ % 4 == 0 ? 4 : 0);
-        dim3 lgrid((unsigned)t_h192);
-#define LAV_HL(F_) LAV_LAUNCH_ONE(gemm_h192l_kernel, true, true, F_, lgrid, HUGE_LDS);
-        if (fsel == S_B) LAV_HL(S_B) else if (fsel == S_BG) LAV_HL(S_BG) else if (fsel == S_GC) LAV_HL(S_GC)
-        else if (fsel == S_BDR) LAV_HL(S_BDR) else LAV_HL(S_BDRO)
-#undef LAV_HL
-        return lav_check_launch("lav_gemm_bf16");
-    }
-    if (big && lav_gemm_q && layout == 0 && fsel != EF_ALL && (N % 128) == 0 && (lav_gemm_q != 9 || (N <= 768 && K >= 2048 && M >= 16384))) {
-        g.k_per_split = K;
-        g.dbg = lav_gemm_dbg;
-        const int tn_ = N / 128;
-        g.group_n = lav_gemm_group_n >= 0 ? lav_gemm_group_n : (lav_gemm_q >= 2 && lav_gemm_q != 9 && tn_ >= lav_gemm_q ? lav_gemm_q : 0);
-        dim3 qgrid((unsigned)((long)((M + 191) / 192) * tn_));
-#define LAV_Q(F_) LAV_LAUNCH_ONE(gemm_q_kernel, true, true, F_, qgrid, Q_LDS);
-        if (fsel == S_B) LAV_Q(S_B) else if (fsel == S_BG) LAV_Q(S_BG) else if (fsel == S_GC) LAV_Q(S_GC)
-        else if (fsel == S_BDR) LAV_Q(S_BDR) else LAV_Q(S_BDRO)
-#undef LAV_Q
-        return lav_check_launch("lav_gemm_bf16");
-    }
-    if (big && !lav_gemm_no_huge && f_h192 > f_huge + 0.02 && f_h192 >= f_big && f_h192 >= f_small) {
+    if (big && f_h192 > f_huge + 0.02 && f_h192 >= f_big && f_h192 >= f_small) {
         g.k_per_split = K;
         g.dbg = lav_gemm_dbg; g.group_n = 0;
         dim3 hgrid((unsigned)t_h192);
-        if (layout == 0 && lav_gemm_h192l && lav_gemm_pers) {
-            if (fsel == S_BDRO) LAV_PERS_ONE(gemm_p192_kernel, 512, S_BDRO, t_h192);
-            else LAV_LAUNCH_PERS(gemm_p192l_kernel, 640, t_h192);
-            return lav_check_launch("lav_gemm_bf16");
-        }
 #define LAV_H192(F_) { if (layout == 0 && lav_gemm_h192l) LAV_LAUNCH_ONE(gemm_h192l_kernel, true, true, F_, hgrid, HUGE_LDS); else if (layout == 0) LAV_LAUNCH_ONE(gemm_h192_kernel, true, true, F_, hgrid, HUGE_LDS); else LAV_LAUNCH_ONE(gemm_h192_kernel, true, false, F_, hgrid, HUGE_LDS); }
         if (fsel == S_B) LAV_H192(S_B) else if (fsel == S_BG) LAV_H192(S_BG) else if (fsel == S_GC) LAV_H192(S_GC)
         else if (fsel == S_BDR) LAV_H192(S_BDR) else LAV_H192(S_BDRO)
 #undef LAV_H192
         return lav_check_launch("lav_gemm_bf16");
     }
-    if (big && !lav_gemm_no_huge && f_huge >= f_big && f_huge >= f_small) {
+    if (big && f_huge >= f_big && f_huge >= f_small) {
         g.k_per_split = K;
         dim3 hgrid((unsigned)t_huge);
-        if (lav_gemm_pp && layout == 0 && fsel != EF_ALL) {
-            if (lav_gemm_pp_dbg) {
-                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-                hipFuncSetAttribute((const void*)gemm_pp_kernel<false, S_B, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-                (void)hipGetLastError();
-                switch (lav_gemm_pp_dbg) {
-                    case 1: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 1>), hgrid, dim3(512), PP_LDS, s, g); break;
-                    case 2: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 2>), hgrid, dim3(512), PP_LDS, s, g); break;
-                    case 3: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 3>), hgrid, dim3(512), PP_LDS, s, g); break;
-                    case 4: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 4>), hgrid, dim3(512), PP_LDS, s, g); break;
-                    case 5: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 5>), hgrid, dim3(512), PP_LDS, s, g); break;
-                    default: hipLaunchKernelGGL((gemm_pp_kernel<false, S_B, 6>), hgrid, dim3(512), PP_LDS, s, g); break;
-                }
-                return lav_check_launch("lav_gemm_bf16");
-            }
-            LAV_LAUNCH_PP(hgrid);
-            return lav_check_launch("lav_gemm_bf16");
-        }
         g.dbg = lav_gemm_dbg;
         if (layout != 2) {
             const int tn_ = N / 256;
             g.group_n = lav_gemm_group_n >= 0 ? lav_gemm_group_n : (tn_ >= 8 && tn_ % 4 == 0 ? 4 : 0);
         }
-        if (layout == 0 && lav_gemm_pers && fsel != EF_ALL) {
-            LAV_LAUNCH_PERS(gemm_p256_kernel, 512, t_huge);
-            return lav_check_launch("lav_gemm_bf16");
-        }
         LAV_LAUNCH_BY_FEATURES(gemm_huge_kernel, hgrid, HUGE_LDS);
         return lav_check_launch("lav_gemm_bf16");
     }
-    if (big && f_big >= f_small) {
+    if (big && (f_big >= f_small || g.nb_rows)) {
         dim3 bgrid(((M + BIG_BM - 1) / BIG_BM) * ((N + BN - 1) / BN));
         g.k_per_split = K;
         LAV_LAUNCH_BY_FEATURES(gemm_big_kernel, bgrid, BIG_LDS);
@@ -1956,7 +1592,7 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     }
     if (layout != 2) {
         const bool sk = splits > 1 && g.e.out_mode == 0;     // under-filled long-K problem (vocabulary contraction): workspace split-K
-        const bool sk_huge = sk && (K % BKT) == 0 && (kps % BKT) == 0 && M >= 256 && (N % 256) == 0 && !lav_gemm_force_small;
+        const bool sk_huge = sk && (K % BKT) == 0 && (kps % BKT) == 0 && M >= 256 && (N % 256) == 0;
         const int rpt = sk_huge ? BIG_BM : BM;
         const int ws_tiles = ((M + rpt - 1) / rpt) * ((N + BN - 1) / BN);
         if (sk) {
@@ -1978,23 +1614,23 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     } else {
         // ---- weight gradients -------------------------------------------------------------------------------------
         // flush (out_mode 2): one block per output tile -> plain read-modify-write; split-K -> private partial tiles in a
-        // workspace + one reduction pass.  fp32 atomics only remain for ragged N or LAV_GEMM_ATOMIC_FLUSH=1.
+        // workspace + one reduction pass.  fp32 atomics only remain for ragged N.
         const bool plain = g.e.out_mode == 2 && !g.e.bias && !g.e.act && !g.e.preact && !g.e.gelu_in && g.e.dropout_p <= 0.f &&
                            !g.e.row_scale && !g.e.residual && !g.e.colsum;
         int kind = 0;                                        // 0: 128x128 two-group kernel, 1: 256x128, 2: 256x256
-        const bool large_ok = plain && (K % BKT) == 0 && (kps % BKT) == 0 && M >= 256 && !lav_gemm_force_small &&
+        const bool large_ok = plain && (K % BKT) == 0 && (kps % BKT) == 0 && M >= 256 &&
                               (!g.e.k_keep || g.e.k_rows_per_group >= BKT);
         if (large_ok && lav_gemm_tn_kind != 0) kind = (N % 256) == 0 && lav_gemm_tn_kind != 1 ? 2 : 1;
         // contraction lengths that are multiples of 32 but not of 64 (Swin stage 3: 7840 token rows): the ping-pong kernel walks k-tiles of 32
         // (k_per_split is a multiple of 64, so only the last split ends on a 32-boundary) -- before round 4 these fell to the 128 x 128 kernel
-        const bool pp_only = !large_ok && plain && (K % PP_BK) == 0 && (K % BKT) != 0 && M >= 256 && (N % 256) == 0 && !lav_gemm_force_small &&
+        const bool pp_only = !large_ok && plain && (K % PP_BK) == 0 && (K % BKT) != 0 && M >= 256 && (N % 256) == 0 &&
                              lav_gemm_pp_tn && lav_gemm_tn_kind != 0 && lav_gemm_tn_kind != 1 &&
                              (!g.e.k_keep || (g.e.k_rows_per_group >= BKT && (K + g.e.k_rows_per_group - 1) / g.e.k_rows_per_group <= 128));
         if (pp_only) kind = 2;
         const int rpt = kind ? BIG_BM : BM;
         const int ws_tiles = ((M + rpt - 1) / rpt) * ((N + BN - 1) / BN);
         bool reduce = false;
-        if (g.e.out_mode == 2 && !lav_gemm_atomic_flush) {
+        if (g.e.out_mode == 2) {
             if (splits == 1) g.owner = 1;
             else if ((N % 4) == 0 && (ldc % 4) == 0) {
                 float* ws = splitk_workspace(stream, (size_t)splits * ws_tiles * rpt * BN * sizeof(float));

@@ -57,6 +57,11 @@ STREAM32 = os.environ.get("LAV_STREAM32", "1") != "0"
 # saved pre-LayerNorm rows + (mean, rstd, gamma, beta) and adds LayerNorm(rows) itself (lav_gemm_epilogue.res_ln_*; same
 # arithmetic, same bits).  138 MB less written per LayerNorm at the cfg2 shape.  LAV_RESLN=0 restores the fp32 LayerNorm output.
 RESLN = STREAM32 and os.environ.get("LAV_RESLN", "1") != "0"
+# Swin blocks whose windows run the persistent kernels (<= 256 tokens, head_dim 32: every Swin-T / Swin-B stage) keep their fused
+# q | k | v projection HEAD-MAJOR -- [q | k | v][head][token][32], written that way by the QKV GEMM epilogue (lav_gemm_epilogue.hm_*) --
+# so that a window's operand pieces are whole 128-byte lines instead of 64-byte halves of the (rows, 3C) rows.  Only the attention
+# kernels read qkv (its gradient dqkv stays row-major: it is a GEMM operand).  LAV_QKV_HEADMAJOR=0 restores the row-major layout.
+QKV_HEADMAJOR = os.environ.get("LAV_QKV_HEADMAJOR", "1") != "0"
 
 
 def dw_stream(device):
@@ -180,9 +185,11 @@ class SwinBlockFn(torch.autograd.Function):
             y1 = K.gather_rows(y1, to_pad, Ma, C)
         else:
             Ma = M
-        qkv = K.gemm(0, y1, W16(a.qkv.weight), Ma, 3 * C, C, bias=a.qkv.bias.data)
+        hm = QKV_HEADMAJOR and C // heads == 32 and win[0] * win[1] * win[2] <= 256
+        qkv = K.gemm(0, y1, W16(a.qkv.weight), Ma, 3 * C, C, bias=a.qkv.bias.data, headmajor=(heads, 32) if hm else None)
         att = K.Attn(0, heads, C // heads, B=B, D=D, H=H, W=Wd, wd=win[0], wh=win[1], ww=win[2], sd=sh[0], sh=sh[1],
-                     sw=sh[2], cfg_wd=cfg[0], cfg_wh=cfg[1], cfg_ww=cfg[2], bias_table=a.relative_position_bias_table.data)
+                     sw=sh[2], cfg_wd=cfg[0], cfg_wh=cfg[1], cfg_ww=cfg[2], bias_table=a.relative_position_bias_table.data,
+                     qkv_headmajor=int(hm))
         lse = torch.empty(att.lse_elems(), dtype=torch.float32, device=x.device) if keep else None
         ao = torch.empty((Ma, C), dtype=bf16, device=x.device)
         att.fwd(qkv, ao, lse)
@@ -494,6 +501,9 @@ class BertLayerFn(torch.autograd.Function):
         outputs -- see model._encode)."""
         Hd = x.shape[1]
         R = n * L
+        # the extra outputs (pre2 / mean2 / rstd2 or y32) are non-differentiable carriers: without this autograd hands the backward a
+        # zero-filled tensor for each of them -- 36 fills per step, twelve of them 138 MB (0.5 ms per step in the r03 kernel trace)
+        ctx.set_materialize_grads(False)
         rowmap = pair[0] if pair is not None else None
         assert pair is not None or x.shape[0] == R
         f32 = torch.float32
@@ -540,6 +550,8 @@ class BertLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *_unused):
+        if dy is None:                                     # nothing downstream used the layer output (grads are not materialised, see forward)
+            return (None,) * 12
         layer, att, (s1, s2), p = ctx.layer, ctx.att, ctx.seeds, ctx.p
         x, qkv, cx, lse, pre1, mean1, rstd1, x1, h_pre, h, pre2, mean2, rstd2 = ctx.saved_tensors
         R, Hd = cx.shape
@@ -602,7 +614,7 @@ class MLMHeadFn(torch.autograd.Function):
                                          want_stats=keep)
         ld = (V + 7) // 8 * 8
         buf = torch.empty((R, ld), dtype=bf16, device=x.device)
-        K.gemm(0, tn, W16(dec.weight), R, V, Hd, out=buf, bias=dec.bias.data)
+        K.gemm(0, tn, W16(dec.weight), R, V, Hd, out=buf, bias=dec.bias.data, c_pad_writable=True)   # the 6 padding columns of buf are never read as logits
         ctx.head, ctx.shp, ctx.split = head, shp, split
         ctx.save_for_backward(x2, t_pre, t, mean, rstd, tn)
         if split is None:

@@ -40,48 +40,66 @@ def _ld(t):
     return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
 
 
+import struct as _struct
+import threading as _threading
+
+# lav_gemm_epilogue, packed in ONE struct.pack_into instead of ~30 ctypes field stores (13 -> ~6 us per call on ~450 calls per step:
+# the launch thread's Python time is what the step falls back on when the GPU gets faster).  Native alignment ("@") reproduces the C
+# layout; tests/test_host_logic.py holds the format to ctypes' own view of the struct, field by field.
+_EPI_FIELDS = ("bias", "act", "preact", "ldp", "gelu_in", "ldg", "dropout_p", "seed", "row_scale", "rows_per_group", "residual", "ldr",
+               "colsum", "alpha", "out_mode", "k_keep", "k_rows_per_group", "rowsum_a", "preact_is_grad", "gelu_in_is_grad", "residual_f32",
+               "a_rowmap", "res_rowmap", "res_ln_mean", "res_ln_rstd", "res_ln_gamma", "res_ln_beta", "hm_heads", "hm_head_dim", "hm_rows",
+               "c_pad_writable")
+_EPI_PACK = _struct.Struct("@PiPqPqfIPiPqPfiPiPiiiPPPPPPiiqi")
+assert tuple(f[0] for f in L.GemmEpilogue._fields_) == _EPI_FIELDS and _EPI_PACK.size <= C.sizeof(L.GemmEpilogue)
+_tls = _threading.local()
+
+
+def _epi_buffer():
+    b = getattr(_tls, "epi", None)
+    if b is None:
+        raw = C.create_string_buffer(C.sizeof(L.GemmEpilogue))
+        b = _tls.epi = (raw, C.cast(raw, C.POINTER(L.GemmEpilogue)))
+    return b
+
+
+def _dp(t):
+    return 0 if t is None else t.data_ptr()
+
+
 def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, preact=None, gelu_in=None, dropout_p=0.0,
          seed=0, row_scale=None, rows_per_group=1, residual=None, colsum=None, alpha=1.0, accumulate=False,
          k_keep=None, k_rows_per_group=1, splits=1, ldc=None, rowsum_a=None, preact_is_grad=False, gelu_in_is_grad=False,
-         a_rowmap=None, res_rowmap=None, res_ln=None):
+         a_rowmap=None, res_rowmap=None, res_ln=None, c_pad_writable=False, headmajor=None):
     """layout 0: A[M,K] B[N,K]; 1: A[M,K] B[K,N]; 2: A[K,M] B[K,N].  Returns the (M, N) output view.
     a_rowmap / res_rowmap (int32 [M]): logical row m of A / of the residual is physical row map[m] (pair expansion, layout 0).
-    res_ln = (mean, rstd, gamma, beta): `residual` (fp32) is a PRE-LayerNorm tensor, the epilogue adds LayerNorm(residual)."""
-    dev = A.device
+    res_ln = (mean, rstd, gamma, beta): `residual` (fp32) is a PRE-LayerNorm tensor, the epilogue adds LayerNorm(residual).
+    headmajor = (heads, head_dim): bf16 output stored [plane][head][row][head_dim] (lav_gemm_epilogue.hm_*); `out` is then just M * N elements.
+    c_pad_writable: N % 8 != 0 and the padding columns [N, round_up(N, 8)) of `out` may be overwritten (lav_gemm_epilogue.c_pad_writable)."""
     if out is None:
         ldc = ldc or ((N + 7) // 8 * 8)
-        out = torch.empty((M, ldc), dtype=out_dtype, device=dev)
+        out = torch.empty((M, ldc), dtype=out_dtype, device=A.device)
     else:
         ldc = _ld(out)
-    e = L.GemmEpilogue()
-    e.bias = _p(bias)
-    e.act = act
-    e.preact = _p(preact)
-    e.ldp = _ld(preact) if preact is not None else 0
-    e.gelu_in = _p(gelu_in)
-    e.ldg = _ld(gelu_in) if gelu_in is not None else 0
-    e.dropout_p = float(dropout_p)
-    e.seed = int(seed) & 0xFFFFFFFF
-    e.row_scale = _p(row_scale)
-    e.rows_per_group = int(rows_per_group)
-    e.residual = _p(residual)
-    e.ldr = _ld(residual) if residual is not None else 0
-    e.residual_f32 = int(residual is not None and residual.dtype == torch.float32)
-    e.colsum = _p(colsum)
-    e.alpha = float(alpha)
-    e.out_mode = 2 if accumulate else (1 if out.dtype == torch.float32 else 0)
-    e.k_keep = _p(k_keep)
-    e.k_rows_per_group = int(k_rows_per_group)
-    e.rowsum_a = _p(rowsum_a)
-    e.preact_is_grad = int(preact_is_grad)
-    e.gelu_in_is_grad = int(gelu_in_is_grad)
-    e.a_rowmap = _p(a_rowmap)
-    e.res_rowmap = _p(res_rowmap)
+    res32 = residual is not None and residual.dtype == torch.float32
     if res_ln is not None:
-        assert residual is not None and residual.dtype == torch.float32 and out.dtype == torch.float32
-        e.res_ln_mean, e.res_ln_rstd, e.res_ln_gamma, e.res_ln_beta = (_p(t) for t in res_ln)
-    L.check(L.lib.lav_gemm_bf16(_s(), layout, M, N, K, _p(A), _ld(A), _p(B), _ld(B), _p(out), ldc, C.byref(e), splits),
-            "lav_gemm_bf16")
+        assert res32 and out.dtype == torch.float32
+        ln_m, ln_r, ln_g, ln_b = (t.data_ptr() for t in res_ln)
+    else:
+        ln_m = ln_r = ln_g = ln_b = 0
+    hm_h, hm_d, hm_rows = (int(headmajor[0]), int(headmajor[1]), int(M)) if headmajor is not None else (0, 0, 0)
+    raw, ref = _epi_buffer()
+    _EPI_PACK.pack_into(raw, 0,
+                        _dp(bias), act, _dp(preact), _ld(preact) if preact is not None else 0,
+                        _dp(gelu_in), _ld(gelu_in) if gelu_in is not None else 0,
+                        float(dropout_p), int(seed) & 0xFFFFFFFF, _dp(row_scale), int(rows_per_group),
+                        _dp(residual), _ld(residual) if residual is not None else 0, _dp(colsum), float(alpha),
+                        2 if accumulate else (1 if out.dtype == torch.float32 else 0),
+                        _dp(k_keep), int(k_rows_per_group), _dp(rowsum_a), int(preact_is_grad), int(gelu_in_is_grad), int(res32),
+                        _dp(a_rowmap), _dp(res_rowmap), ln_m, ln_r, ln_g, ln_b, hm_h, hm_d, hm_rows, int(bool(c_pad_writable)))
+    rc = L.lib.lav_gemm_bf16(_s(), layout, M, N, K, A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), out.data_ptr(), ldc, ref, splits)
+    if rc != 0:
+        L.check(rc, "lav_gemm_bf16")
     return out[:, :N] if out.shape[-1] != N else out
 
 

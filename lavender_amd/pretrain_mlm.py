@@ -146,7 +146,7 @@ class Agent_Pretrain_MLM(Agent_Base):
 
     def step(self, batch, is_train=True, sync=True):
         """main_pretrain_mlm.py:145-176.  sync=False returns the two losses as device scalars (no host round trip)."""
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         n_mtm = batch.get("_n_mtm") if isinstance(batch, dict) else None
         with torch.set_grad_enabled(is_train):
             out = self.forward_step(batch)
@@ -179,7 +179,7 @@ class Agent_Pretrain_MLM(Agent_Base):
 
     def go_dl(self, ep, dl, is_train):
         """main_pretrain_mlm.py:202-232."""
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         ret = defaultdict(list)
         idx = 0
         for idx, batch in enumerate(dl):

@@ -96,7 +96,7 @@ class Agent_Pretrain(Agent_Base):
 
     def step(self, batch, is_train=True, sync=True):
         """main_pretrain_task_specific.py:211-248."""
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         img, txt, mask = [batch[key] for key in ["img", "txt", "mask"]]
         ans_mtm = batch["ans_mtm"]
         n_mtm = batch.get("_n_mtm")
@@ -119,7 +119,7 @@ class Agent_Pretrain(Agent_Base):
 
     def go_dl(self, ep, dl, is_train):
         """main_pretrain_task_specific.py:250-262 (+ masking as in its collate path)."""
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         ret = defaultdict(list)
         for batch in dl:
             batch = dict(batch)

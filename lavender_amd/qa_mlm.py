@@ -79,7 +79,7 @@ class Agent_RetMC_MLM(Agent_Base):
 
     def step(self, batch, is_train):
         """main_retmc_mlm.py:120-140."""
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         n_lab = batch.pop("_n_lab", None) if isinstance(batch, dict) else None
         with torch.set_grad_enabled(is_train):
             out, ans = self.forward_step(batch)
@@ -98,7 +98,7 @@ class Agent_RetMC_MLM(Agent_Base):
         return (out_mtm == ans_idx).float().tolist()
 
     def go_dl(self, ep, dl, is_train):
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         ret = []
         for batch in dl:
             r = self.step(self.prepare_batch(dict(batch)), is_train)
@@ -113,7 +113,7 @@ class Agent_QAOE_MLM(Agent_Base):
 
     def step(self, batch, is_train):
         """main_qaoe_mlm_lsmdc_fib.py:100-113."""
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         n_lab = batch.pop("_n_lab", None) if isinstance(batch, dict) else None
         with torch.set_grad_enabled(is_train):
             out, ans = self.forward_step(batch)
@@ -142,7 +142,7 @@ class Agent_QAOE_MLM(Agent_Base):
 
     def go_dl(self, ep, dl, is_train):
         """main_qaoe_mlm.py:96-125."""
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         ret = {}
         for batch in dl:
             r = self.step(self.prepare_batch(dict(batch)), is_train)
@@ -165,7 +165,7 @@ class Agent_QAMC_MLM(Agent_Base):
 
     def step(self, batch, is_train):
         """main_qamc_mlm.py:148-170."""
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         n_lab = batch.pop("_n_lab", None) if isinstance(batch, dict) else None
         with torch.set_grad_enabled(is_train):
             out, ans = self.forward_step(batch)
@@ -181,7 +181,7 @@ class Agent_QAMC_MLM(Agent_Base):
 
     def go_dl(self, ep, dl, is_train):
         """main_qamc_mlm.py:172-207."""
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         ret = []
         for batch in dl:
             r = self.step(self.prepare_batch(dict(batch)), is_train)

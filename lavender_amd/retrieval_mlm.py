@@ -57,7 +57,7 @@ class Agent_Retrieval_MLM(Agent_Base):
 
     def step(self, batch, is_train, sync=True):
         """main_retrieval_mlm.py:99-118.  sync=False returns the training loss as a device scalar (no host round trip per step)."""
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         with torch.set_grad_enabled(is_train):
             out, ans = self.forward_step(batch)
             if is_train:
@@ -78,7 +78,7 @@ class Agent_Retrieval_MLM(Agent_Base):
 
     def go_dl(self, ep, dl, is_train):
         """main_retrieval_mlm.py:120-150."""
-        self.model.train() if is_train else self.model.eval()
+        self._set_mode(is_train)
         ret = []
         for batch in dl:
             batch = self.prepare_batch(dict(batch))

@@ -64,11 +64,10 @@ def test_gemm_large_m_kernels(layout, shape):
 
 @pytest.mark.parametrize("shape,flags", [((8448, 2048, 128), "bGp"), ((8448, 2048, 192), "bdrO"), ((45120, 768, 128), "bdr"),
                                          ((45120, 768, 64), "gsc"), ((70000, 256, 64), "b")])
-def test_gemm_persistent_tile_walk(shape, flags):
-    """Round 4: outputs with more 256 (192) x 256 tiles than CUs run the PERSISTENT kernels (gemm_p256 / gemm_p192l: one workgroup per
-    CU walks several tiles, the next tile's first operand stage is in flight under the current epilogue, the epilogue stages through
-    the LDS behind it).  Against the fp32 reference, and bit-identical to the one-tile-per-workgroup kernels (lav_gemm_select(10, 0))."""
-    from lavender_amd import _lib as L
+def test_gemm_many_tiles_per_cu(shape, flags):
+    """Outputs with more 256 (192) x 256 tiles than CUs (several rounds of workgroups; the B = 32 shapes of the benchmark step: 45120-row
+    fusion GEMMs on the 192-row loader-wave tiles, column sums accumulated over a tile's row chunks before the flush) with every
+    specialised epilogue, against the fp32 reference."""
     M, N, Kd = shape
     A, W = rb(M, Kd), rb(N, Kd, seed=1, scale=0.2)
     o32 = "O" in flags
@@ -79,40 +78,28 @@ def test_gemm_persistent_tile_walk(shape, flags):
     if "d" in flags: kw["dropout_p"] = 0.1; kw["seed"] = 4321
     if "s" in flags: kw["row_scale"] = (torch.tensor([1.25, 0.0, 1.25, 1.25] * 8)).cuda(); kw["rows_per_group"] = (M + 31) // 32
     if "r" in flags: kw["residual"] = rb(M, N, seed=2).float() if o32 else rb(M, N, seed=2)
-    res = {}
-    for mode in (1, 0):
-        old = L.lib.lav_gemm_select(10, mode)
-        try:
-            k2 = dict(kw)
-            if "p" in flags: k2["preact"] = torch.zeros(M, N, dtype=bf16, device="cuda"); k2["preact_is_grad"] = 1
-            if "c" in flags: k2["colsum"] = torch.zeros(N, device="cuda")
-            out = K().gemm(0, A, W, M, N, Kd, out_dtype=torch.float32 if o32 else bf16, **k2)
-            torch.cuda.synchronize()
-        finally:
-            L.lib.lav_gemm_select(10, old)
-        res[mode] = (out, k2.get("preact"), k2.get("colsum"))
-    assert torch.equal(res[0][0], res[1][0]), "persistent vs one-tile kernels differ"
-    if res[0][1] is not None:
-        assert torch.equal(res[0][1], res[1][1])
+    if "p" in flags: kw["preact"] = torch.zeros(M, N, dtype=bf16, device="cuda"); kw["preact_is_grad"] = 1
+    if "c" in flags: kw["colsum"] = torch.zeros(N, device="cuda")
+    out = K().gemm(0, A, W, M, N, Kd, out_dtype=torch.float32 if o32 else bf16, **kw)
+    torch.cuda.synchronize()
     z = A.float() @ W.float().t()
     if "b" in flags: z = z + kw["bias"]
-    if flags in ("bGp",):
+    if flags == "bGp":
         hh = z.detach().clone().requires_grad_(True)
         y = F.gelu(hh); y.sum().backward()
-        close(res[1][0], y.detach(), atol=3e-2, what="persistent gelu")
-        close(res[1][1], hh.grad, atol=3e-2, what="persistent stored gelu'")
+        close(out, y.detach(), atol=3e-2, what="gelu")
+        close(kw["preact"], hh.grad, atol=3e-2, what="stored gelu'")
     elif flags == "b":
-        close(res[1][0], z, atol=3e-2, what="persistent bias")
+        close(out, z, atol=3e-2, what="bias")
     elif flags == "gsc":
         ref = z * kw["gelu_in"].float() * kw["row_scale"].repeat_interleave(kw["rows_per_group"])[:M, None]
-        close(res[1][0], ref, atol=3e-2, what="persistent gelu' x row scale")
-        close(res[1][2], ref.sum(0), atol=2.0, rtol=2e-2, what="persistent colsum")
-        close(res[0][2], ref.sum(0), atol=2.0, rtol=2e-2, what="one-tile colsum")
+        close(out, ref, atol=3e-2, what="gelu' x row scale")
+        close(kw["colsum"], ref.sum(0), atol=2.0, rtol=2e-2, what="colsum")
     else:                                                  # dropout: the kept elements are (z / 0.9 + residual), the dropped ones the residual
-        o, r = res[1][0].float(), kw["residual"].float()
+        o, r = out.float(), kw["residual"].float()
         kept = (o - r).abs() > 0
         assert 0.88 < kept.float().mean().item() < 0.92
-        close(torch.where(kept, o, r + z / 0.9), r + z / 0.9, atol=3e-2, what="persistent dropout + residual")
+        close(torch.where(kept, o, r + z / 0.9), r + z / 0.9, atol=3e-2, what="dropout + residual")
 
 
 @pytest.mark.parametrize("splits", [1, 3])
@@ -317,6 +304,28 @@ def test_gemm_ragged_vocab_tail():
     close(dX, buf[:, :V].float() @ W.float(), atol=5e-2, what="ragged K")
 
 
+def test_gemm_ragged_vocab_with_writable_padding():
+    """lav_gemm_epilogue.c_pad_writable: the vocabulary projection (N % 8 == 2, like 30522) into its row-padded logits buffer on the
+    large-tile kernel with full 16-byte chunks.  The N real columns are exact; W and bias are read for N entries only (the buffers end
+    right after them: a guard region behind W stays NaN-free in the result); padding columns may hold anything finite."""
+    M, V, Kd = 2304, 1018, 128
+    ld = (V + 7) // 8 * 8
+    X = rb(M, Kd)
+    wfull = torch.full(((V + 8) * Kd,), float("nan"), dtype=bf16, device="cuda")      # rows past V are poison
+    W = wfull[:V * Kd].view(V, Kd)
+    W.copy_(rb(V, Kd, seed=1, scale=0.1))
+    bfull = torch.full((V + 8,), float("nan"), device="cuda")
+    bias = bfull[:V]
+    bias.copy_(torch.randn(V))
+    buf = torch.full((M, ld), 7.0, dtype=bf16, device="cuda")
+    K().gemm(0, X, W, M, V, Kd, out=buf, bias=bias, c_pad_writable=True)
+    close(buf[:, :V], X.float() @ W.float().t() + bias, what="ragged N, writable padding")
+    assert torch.isfinite(buf.float()).all()
+    ref = torch.full((M, ld), 7.0, dtype=bf16, device="cuda")
+    K().gemm(0, X, W, M, V, Kd, out=ref, bias=bias)                      # the generic ragged-N path: same values in the real columns
+    assert torch.equal(ref[:, :V], buf[:, :V]) and (ref[:, V:] == 7.0).all()
+
+
 def test_gemm_dropout_mask_consistent_with_layernorm_bwd():
     """The GEMM epilogue and the LN backward regenerate the SAME counter-based dropout mask."""
     M, N, Kd, p, seed = 256, 128, 64, 0.3, 1234
@@ -479,6 +488,60 @@ def test_window_attention_fwd_bwd(case):
             _lib.lib.lav_winl_select(old_parts)
     else:
         _window_attention_check(att, case, qkv, table, cfg)
+
+
+@pytest.mark.parametrize("case", [
+    (2, 5, 14, 14, 64, 2, (5, 7, 7), (0, 3, 3)),        # N=245 shifted
+    (3, 5, 14, 14, 128, 4, (5, 7, 7), (0, 0, 0)),       # four heads, unshifted
+    (2, 1, 14, 14, 32, 1, (1, 7, 7), (0, 3, 3)),        # N=49
+    (2, 4, 14, 7, 96, 3, (4, 7, 7), (0, 3, 0)),         # N=196, three heads
+])
+def test_window_attention_head_major_qkv(case):
+    """Round 4: the persistent window kernels fetch q / k / v from a HEAD-MAJOR operand [q | k | v][head][token][32]
+    (lav_attn_desc.qkv_headmajor; the QKV GEMM epilogue writes it, lav_gemm_epilogue.hm_*): forward, dQ / dK / dV and the split
+    bias-table gradient are bit-identical to the row-major layout on the same values."""
+    B, D, H, W, C, heads, win, shift = case
+    cfg = (8, 7, 7)
+    M = B * D * H * W
+    qkv = rb(M, 3 * C)
+    qkv_hm = qkv.view(M, 3, heads, 32).permute(1, 2, 0, 3).contiguous().view(M, 3 * C)     # same bytes count, head-major order
+    table = (0.5 * torch.randn((2 * cfg[0] - 1) * (2 * cfg[1] - 1) * (2 * cfg[2] - 1), heads)).cuda()
+    dout = rb(M, C, seed=9)
+    res = []
+    for hm, x in ((0, qkv), (1, qkv_hm)):
+        att = K().Attn(0, heads, 32, B=B, D=D, H=H, W=W, wd=win[0], wh=win[1], ww=win[2], sd=shift[0], sh=shift[1], sw=shift[2],
+                       cfg_wd=cfg[0], cfg_wh=cfg[1], cfg_ww=cfg[2], bias_table=table, qkv_headmajor=hm)
+        lse = torch.empty(att.lse_elems(), device="cuda")
+        out = torch.empty(M, C, dtype=bf16, device="cuda")
+        att.fwd(x, out, lse)
+        dqkv, dtab = torch.empty(M, 3 * C, dtype=bf16, device="cuda"), torch.zeros_like(table)
+        att.bwd(x, out, dout, lse, dqkv, None)
+        att.bwd_bias(x, dout, lse, dtab)
+        torch.cuda.synchronize()
+        res.append((out, dqkv, dtab))
+    assert torch.equal(res[0][0], res[1][0]), "forward differs between the layouts"
+    assert torch.equal(res[0][1], res[1][1]), "dqkv (row-major in both cases) differs"
+    assert torch.allclose(res[0][2], res[1][2], rtol=1e-4, atol=1e-4), "bias-table gradient differs"      # fp32 atomics across workgroups
+    # and the reference, once
+    qr = qkv.float().cpu().requires_grad_(True)
+    tr = table.float().cpu().requires_grad_(True)
+    ref = _win_ref(qr, tr, B, D, H, W, C, heads, win, shift, cfg)
+    close(res[1][0], ref, atol=2e-2, what=f"head-major window fwd {case}")
+    ref.backward(dout.float().cpu())
+    close(res[1][1], qr.grad, atol=4e-2, rtol=4e-2, what=f"head-major window dqkv {case}")
+
+
+def test_gemm_head_major_store():
+    """lav_gemm_epilogue.hm_*: the fused q | k | v projection stored as [q | k | v][head][row][32] -- through the 256-wide tile kernel
+    (M >= 2048, N % 256 == 0), the 256 x 128 one and the generic 128 x 128 one (ragged M)."""
+    for M, heads, Kd in ((2304, 8, 128), (2500, 4, 64), (300, 2, 96), (77, 1, 64)):
+        C = heads * 32
+        X, W = rb(M, Kd), rb(3 * C, Kd, seed=1, scale=0.2)
+        bias = torch.randn(3 * C).cuda()
+        ref = K().gemm(0, X, W, M, 3 * C, Kd, bias=bias)
+        hm = K().gemm(0, X, W, M, 3 * C, Kd, bias=bias, headmajor=(heads, 32))
+        assert torch.equal(hm.reshape(3, heads, M, 32).permute(2, 0, 1, 3).reshape(M, 3 * C), ref), (M, heads, Kd)
+        close(ref, X.float() @ W.float().t() + bias, what="qkv projection")
 
 
 def _window_attention_check(att, case, qkv, table, cfg):

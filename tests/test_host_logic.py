@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(_lib.lib, name), f"{name} declared in lavender_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.lib.lav_abi_version() == 3
+    assert _lib.lib.lav_abi_version() == 4
 
 
 def test_argument_errors_are_reported_not_thrown():
@@ -320,3 +320,30 @@ def test_loader_sampler_orders_match_torch_samplers():
         torch.manual_seed(11)
         assert _Sampler(n, True, False).indices() == a
         assert _Sampler(n, False, False).indices() == list(SequentialSampler(DS(n)))
+
+
+def test_gemm_epilogue_pack_format_matches_the_c_struct():
+    """hip.gemm fills lav_gemm_epilogue with one struct.pack_into (lavender_amd/hip.py:_EPI_PACK): every field must land where the
+    ctypes declaration of the struct (= the C layout, include/lavender_hip.h) puts it, with the value it was given."""
+    import ctypes as C
+    import struct
+    from lavender_amd import _lib as L, hip as K
+    fields = [f[0] for f in L.GemmEpilogue._fields_]
+    assert tuple(fields) == K._EPI_FIELDS
+    vals = []
+    for i, (name, ct) in enumerate(L.GemmEpilogue._fields_):
+        if ct is L.f32:
+            vals.append(0.5 + i)
+        elif ct is L.vp:
+            vals.append(0x1000_0000_0000 + 16 * i)
+        elif ct is L.u32:
+            vals.append(0xF000_0000 + i)
+        else:
+            vals.append(1000 + i)
+    raw = C.create_string_buffer(C.sizeof(L.GemmEpilogue))
+    K._EPI_PACK.pack_into(raw, 0, *vals)
+    st = C.cast(raw, C.POINTER(L.GemmEpilogue)).contents
+    for name, v in zip(fields, vals):
+        got = getattr(st, name)
+        assert (got or 0) == v, (name, got, v)
+    assert K._EPI_PACK.size <= C.sizeof(L.GemmEpilogue) < K._EPI_PACK.size + 8          # only tail padding may differ
