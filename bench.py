@@ -162,6 +162,7 @@ def main():
                     help="opt-in side measurement (NOT the contract line): MLM head + loss on the supervised positions only")
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-loop", action="store_true", help="skip the ms_per_step_reference_loop leg (profile collection: keeps the step count of the run fixed)")
     ap.add_argument("--force-dp", action="store_true",
                     help="side measurement at --gpus 1: join a 1-rank RCCL process group and attach the gradient reducer (what the "
                          "overlap bookkeeping and the comm-stream events cost when there is nobody to talk to)")
@@ -317,7 +318,7 @@ def main():
     # step a HOST batch (pinned, as a DataLoader with pin_memory hands it over), masking() on the host, prepare_batch (H2D of frames,
     # ids, labels) and .item() on both losses -- i.e. one device round trip per step and no enqueue run-ahead
     ref_loop_ms = None
-    if not retrieval and feed is None and use_cuda:
+    if not retrieval and feed is None and use_cuda and not a.no_ref_loop:
         host_batches = []
         for i in range(nb):
             hb = synth_batch(B, T, S, X, rank * 7 + i, "cpu")
@@ -396,7 +397,7 @@ def main():
         for lay_i, fl_i, e0_i, e1_i, _nb_i in rec_iso:
             if lay_i == 0:
                 iso[0] += 1; iso[1] += fl_i; iso[2] += e0_i.elapsed_time(e1_i) * 1e-3
-        roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T and input-gradient dy.(W^T)^T GEMMs: gemm_p256 / gemm_p192l persistent tile walkers, gemm_huge / gemm_big / gemm_kernel<NT>)",
+        roof = {"bound": "mfma", "kernel": "lav_gemm_bf16 layout 0 (forward x.W^T and input-gradient dy.(W^T)^T GEMMs: gemm_huge / gemm_h192l / gemm_big / gemm_kernel<NT>)",
                 "achieved": round(fl / tm / 1e12, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tm / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_unit": f"HBM bytes per launch, STATIC: read from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE, profiles/{TRAFFIC_FILE}.md), not collected in this run",

@@ -570,6 +570,10 @@ def _window_attention_check(att, case, qkv, table, cfg):
         assert torch.equal(dqkv2, dqkv)
         rel2 = (dtab2.cpu() - tr.grad).norm() / tr.grad.norm()
         assert rel2 < 2e-2, f"bias-table gradient (split launch) rel err {rel2.item():.3g}"
+        # split launch vs the launch that produces it inside lav_attention_bwd: the same kernel arithmetic, only the order of the fp32
+        # atomics across workgroups differs
+        rel3 = ((dtab2 - dtab).norm() / dtab.norm()).item()
+        assert rel3 < 1e-5, f"split vs fused bias-table gradient differ by {rel3:.3g}"
 
 
 def _seq_ref(qkv, mask, n, L, heads):
@@ -644,6 +648,79 @@ def test_sequence_attention_dropout_statistics():
         outs.append(out.float())
     assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])     # pure function of the seed
     assert abs(outs[0].mean().item() - 1.0) < 0.01 and outs[0].std().item() > 0.01
+
+
+@pytest.mark.parametrize("n,L,heads", [(2, 757, 2), (3, 282, 2), (2, 300, 1)])
+def test_sequence_attention_dropout_same_mask_fwd_bwd(n, L, heads):
+    """Train-mode attention (p = 0.1) of the one-image kernels (L <= 288) AND the chunked long-sequence kernels (288 < L <= 768: cfg4's
+    757 tokens) against torch with the SAME dropout mask, rebuilt on the host from the seed (tests/helpers.attn_keep_multiplier):
+    a forward / backward mismatch of the regenerated mask (drow / dcol index arithmetic of seql_fwd / seql_dq / seql_dkv) shows here."""
+    from tests.helpers import attn_keep_multiplier
+    Hd, p, seed = heads * 64, 0.1, 4242
+    qkv = rb(n * L, 3 * Hd)
+    mask = torch.ones(n, L, dtype=torch.int32)
+    mask[0, L - 5:L - 1] = 0
+    att = K().Attn(1, heads, 64, n_seq=n, L=L, key_mask=mask.cuda(), dropout_p=p, seed=seed)
+    lse = torch.empty(att.lse_elems(), device="cuda")
+    out = torch.empty(n * L, Hd, dtype=bf16, device="cuda")
+    att.fwd(qkv, out, lse)
+    keep = attn_keep_multiplier(seed, n, heads, L, p)                     # (n, heads, L, L): 0 or 1 / (1 - p)
+    qr = qkv.float().cpu().requires_grad_(True)
+    q, k, v = [t.reshape(n, L, heads, 64).transpose(1, 2) for t in qr.split(Hd, -1)]
+    sc = q @ k.transpose(-1, -2) / 8.0 + (1.0 - mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    ref = ((sc.softmax(-1) * keep) @ v).transpose(1, 2).reshape(n * L, Hd)
+    close(out, ref, atol=2.5e-2, what=f"seq fwd with dropout L={L}")
+    dout = rb(n * L, Hd, seed=4)
+    ref.backward(dout.float().cpu())
+    dqkv = torch.empty_like(qkv)
+    att.bwd(qkv, out, dout, lse, dqkv, None)
+    close(dqkv, qr.grad, atol=5e-2, rtol=5e-2, what=f"seq dqkv with dropout L={L}")
+
+
+def test_attention_at_the_benchmark_batch_matches_small_batch_slices():
+    """Size-independent property at the cfg2 bench shapes (B = 32: 2048-window persistent walks per Swin stage-2 launch, 160-sequence
+    fusion batch): a sample's attention output does not depend on the batch it sits in, so the rows of the first two samples / first
+    three sequences must be BIT-identical to a small-batch launch on those rows (eval mode: dropout seeds index by global position)."""
+    # Swin stage 2: 14 x 14 x 5 tokens, C = 512, 16 heads, shifted; row-major and head-major operands
+    D, H, W, C, heads = 5, 14, 14, 512, 16
+    table = (0.5 * torch.randn(2535, heads)).cuda()
+    tps = D * H * W
+    for hm in (0, 1):
+        outs = {}
+        qkv_full = rb(32 * tps, 3 * C)
+        for B in (32, 2):
+            x = qkv_full[:B * tps]
+            if hm:
+                x = x.reshape(B * tps, 3, heads, 32).permute(1, 2, 0, 3).contiguous().view(B * tps, 3 * C)
+            att = K().Attn(0, heads, 32, B=B, D=D, H=H, W=W, wd=5, wh=7, ww=7, sd=0, sh=3, sw=3, cfg_wd=8, cfg_wh=7, cfg_ww=7,
+                           bias_table=table, qkv_headmajor=hm)
+            lse = torch.empty(att.lse_elems(), device="cuda")
+            out = torch.empty(B * tps, C, dtype=bf16, device="cuda")
+            att.fwd(x, out, lse)
+            dout = rb(32 * tps, C, seed=3)[:B * tps]
+            dqkv = torch.empty(B * tps, 3 * C, dtype=bf16, device="cuda")
+            att.bwd(x, out, dout, lse, dqkv, None)
+            torch.cuda.synchronize()
+            outs[B] = (out, dqkv)
+        assert torch.equal(outs[32][0][:2 * tps], outs[2][0]) and torch.equal(outs[32][1][:2 * tps], outs[2][1]), f"window attention, head-major={hm}"
+    # fusion encoder: 160 sequences of 282 tokens, 12 heads
+    L, heads = 282, 12
+    Hd = heads * 64
+    qkv_full = rb(160 * L, 3 * Hd)
+    km = torch.ones(160, L, dtype=torch.int32)
+    km[1, L - 9:L - 1] = 0
+    outs = {}
+    for n in (160, 3):
+        att = K().Attn(1, heads, 64, n_seq=n, L=L, key_mask=km[:n].contiguous().cuda(), dropout_p=0.0, seed=0)
+        lse = torch.empty(att.lse_elems(), device="cuda")
+        out = torch.empty(n * L, Hd, dtype=bf16, device="cuda")
+        x = qkv_full[:n * L]
+        att.fwd(x, out, lse)
+        dqkv = torch.empty_like(x)
+        att.bwd(x, out, rb(160 * L, Hd, seed=5)[:n * L], lse, dqkv, None)
+        torch.cuda.synchronize()
+        outs[n] = (out, dqkv)
+    assert torch.equal(outs[160][0][:3 * L], outs[3][0]) and torch.equal(outs[160][1][:3 * L], outs[3][1]), "fusion attention"
 
 
 # ---------------------------------------------------------------------------------------------- embeddings / gathers

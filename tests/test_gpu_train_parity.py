@@ -26,8 +26,18 @@ def _oracle_case(swin, bert, B, S=224, T=5, X=32):
     return R, P, batch, bc
 
 
+# Per-tensor bounds: the relative-position bias tables are the only tensors whose gradient comes from the split
+# side-stream kernels (win_dbias3 / winl_dbias) and the only ones measured above 2 %; every other tensor gets the tighter OTHER_TOL so
+# that a regression confined to, say, a GEMM epilogue cannot hide under the tables' allowance.
+OTHER_TOL = 0.025
+
+
+def _tol(name, rel_tol):
+    return rel_tol if "relative_position_bias_table" in name else min(rel_tol, OTHER_TOL)
+
+
 def _grad_report(m, P, rel_tol, cos_tol=0.995):
-    bad, worst = [], (None, 0.0)
+    bad, worst, worst_other = [], (None, 0.0), (None, 0.0)
     for name, p in m.named_parameters():
         gref = P[name].grad if name in P else None
         if gref is None:
@@ -41,9 +51,11 @@ def _grad_report(m, P, rel_tol, cos_tol=0.995):
         cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
         if rel > worst[1]:
             worst = (name, rel)
-        if not (rel < rel_tol and cos > cos_tol):
+        if "relative_position_bias_table" not in name and rel > worst_other[1]:
+            worst_other = (name, rel)
+        if not (rel < _tol(name, rel_tol) and cos > cos_tol):
             bad.append((name, round(rel, 4), round(cos, 5), f"{b.norm().item():.2e}"))
-    print("worst relative gradient error:", worst, "| out of tolerance:", bad[:12])
+    print("worst relative gradient error:", worst, "| worst outside the bias tables:", worst_other, "| out of tolerance:", bad[:12])
     return bad
 
 
@@ -226,7 +238,7 @@ def _subset_report(m, P, names, rel_tol, cos_tol):
         rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
         cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
         print(f"{n}: rel {rel:.4f} cos {cos:.5f} |g| {b.norm().item():.2e}")
-        if not (rel < rel_tol and cos > cos_tol):
+        if not (rel < _tol(n, rel_tol) and cos > cos_tol):
             bad.append((n, rel, cos))
     return bad
 
