@@ -2,7 +2,7 @@
 HIPCC ?= hipcc
 ARCH  ?= gfx950
 CSRC  := lavender_amd/csrc
-OBJS  := $(CSRC)/gemm.o $(CSRC)/layernorm.o $(CSRC)/attention.o $(CSRC)/attention_win.o $(CSRC)/attention_seq.o $(CSRC)/attention_winl.o $(CSRC)/embed.o $(CSRC)/loss_optim.o $(CSRC)/validate.o $(CSRC)/pipeline.o $(CSRC)/runtime.o
+OBJS  := $(CSRC)/gemm.o $(CSRC)/layernorm.o $(CSRC)/attention.o $(CSRC)/attention_win.o $(CSRC)/attention_seq.o $(CSRC)/attention_winl.o $(CSRC)/embed.o $(CSRC)/loss_optim.o $(CSRC)/validate.o $(CSRC)/pipeline.o $(CSRC)/runtime.o $(CSRC)/stages.o
 LIB   := lavender_amd/liblavender_hip.so
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value -munsafe-fp-atomics
 
@@ -12,6 +12,9 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/attn_common.h include/lavend
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(CSRC)/runtime.o: $(CSRC)/runtime.cpp $(CSRC)/common.h include/lavender_hip.h
+	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
+
+$(CSRC)/stages.o: $(CSRC)/stages.cpp $(CSRC)/common.h include/lavender_hip.h
 	$(HIPCC) $(FLAGS) -x hip -c $< -o $@
 
 $(LIB): $(OBJS)

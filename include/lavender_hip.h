@@ -95,7 +95,7 @@ int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, 
                   void* C, long ldc, const lav_gemm_epilogue* epi, int splits);
 /* Tuning / probe hook: selects between kernel variants at run time (within-process A/B measurements in tools/): which 2 = ping-pong
  * weight-gradient kernel on/off, 5 = probe bits of the 256x256 kernel (timing only, wrong results), 6 = column-group width of the tile
- * walk, 7 / 9 = 192-row tiles / their loader-wave form on/off, 16-18 = window-attention variants.  Returns the previous value, -1 for
+ * walk, 7 / 9 = 192-row tiles / their loader-wave form on/off.  Returns the previous value, -1 for
  * an unknown selector.  Results are identical up to fp32 summation order (except selector 5). */
 int lav_gemm_select(int which, int value);
 
@@ -343,6 +343,92 @@ int lav_v_text_embed_f32(void* stream, int n, int X, int Hd, const int64_t* ids,
                          const float* type0, const float* gamma, const float* beta, float eps, float* out);
 int lav_v_gather_rows_f32(void* stream, int n_rows, int C, const float* src, long lds_, const int32_t* src_row, float* dst,
                           long ldd);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage-level entries (round 4; SURVEY section 8(b): lav_bert_layer_{fwd,bwd}).  ONE call enqueues every kernel of a stage on the caller's
+ * stream(s) -- the same kernels, in the same order and with the same arguments as the per-kernel entries above would be called by the
+ * host layer (lavender_amd/engine.py), so results are bit-identical; what it removes is ~20 host -> C transitions and their argument
+ * marshalling per stage.  All buffers are the caller's (nothing is allocated here); NULL for an optional buffer means "not wanted".
+ *
+ * One post-LN BertLayer of the fusion encoder (HF BertLayer as called from model.py:242), fp32 residual stream:
+ *   qkv = x Wqkv^T + b;  cx = attention(qkv, key_mask, dropout p_attn);  pre1 = res + dropout(cx Wao^T + b);  x1 = LN1(pre1);
+ *   h = gelu(x1 Wff1^T + b) (+ stored GELU');  pre2 = x1_f32 + dropout(h Wff2^T + b);  y = LN2(pre2)
+ * where `res` is the bf16 input x (first layer) or LayerNorm(res_pre) recomputed from the producing layer's saved pre-LN rows
+ * (res_pre / res_mean / res_rstd / res_gamma / res_beta, see lav_gemm_epilogue.res_ln_*), and x1_f32 = LayerNorm(pre1) likewise.
+ */
+typedef struct lav_bert_layer_desc {
+    int n_seq, L, hidden, heads, ffn;
+    float p_hidden, p_attn, ln_eps;
+    uint32_t seed_attn, seed1, seed2;
+    int causal_from;
+    const int32_t* key_mask;
+    /* parameters: bf16 working copies of the matrices, fp32 vectors */
+    const void* w_qkv; const float* b_qkv;               /* fused (3 hidden, hidden) */
+    const void* w_ao; const float* b_ao; const float* ln1_gamma; const float* ln1_beta;
+    const void* w_ff1; const float* b_ff1;
+    const void* w_ff2; const float* b_ff2; const float* ln2_gamma; const float* ln2_beta;
+    /* input */
+    const void* x;                                         /* bf16 (rows, hidden), rows = n_seq * L */
+    const float* res_pre; const float* res_mean; const float* res_rstd; const float* res_gamma; const float* res_beta;   /* or all NULL */
+    /* outputs / activations kept for the backward (lse, h_pre: NULL in a forward that will not be differentiated) */
+    void* qkv; void* cx; float* lse; float* pre1; float* mean1; float* rstd1; void* x1; void* h_pre; void* h;
+    float* pre2; float* mean2; float* rstd2; void* y;
+} lav_bert_layer_desc;
+int lav_bert_layer_fwd(void* stream, const lav_bert_layer_desc* d);
+
+/* Backward of the same layer.  side_stream (may equal stream, or NULL = stream): the four weight-gradient GEMMs are enqueued there,
+ * each ordered after its operands' producers on `stream` by an event; the caller joins side_stream before it reads the gradients and
+ * keeps their operands (d_dense2, h, dh, x1, d_dense1, cx, dqkv, x) alive until then. */
+typedef struct lav_bert_layer_bwd_desc {
+    lav_bert_layer_desc f;                                 /* the forward's descriptor (saved activations, parameters, seeds) */
+    const void* dy;                                        /* bf16 (rows, hidden) */
+    const void* wt_qkv; const void* wt_ao; const void* wt_ff1; const void* wt_ff2;   /* transposed bf16 copies (in, out) */
+    long ldt_qkv, ldt_ao, ldt_ff1, ldt_ff2;                /* their row pitches */
+    /* fp32 gradient accumulators */
+    float* g_w_qkv; float* g_b_qkv; float* g_w_ao; float* g_b_ao; float* g_ln1_gamma; float* g_ln1_beta;
+    float* g_w_ff1; float* g_b_ff1; float* g_w_ff2; float* g_b_ff2; float* g_ln2_gamma; float* g_ln2_beta;
+    int splits_qkv, splits_ao, splits_ff1, splits_ff2;     /* split-K factors of the weight-gradient GEMMs */
+    /* temporaries (bf16) and the result */
+    void* d_pre2; void* d_dense2; void* dh; void* d_x1; void* d_pre1; void* d_dense1; void* d_cx; void* dqkv;
+    void* dx;                                              /* bf16 (rows, hidden) */
+} lav_bert_layer_bwd_desc;
+int lav_bert_layer_bwd(void* stream, void* side_stream, const lav_bert_layer_bwd_desc* d);
+
+/* One SwinTransformerBlock3D (video_swin.py:204-261) on (rows, C) channels-last tokens whose grid is a multiple of the window (the zero-pad
+ * branches stay with the per-kernel entries):
+ *   y1 = LN1(x);  qkv = y1 Wqkv^T + b;  ao = window_attention(qkv);  x_mid = x + s_attn * (ao Wproj^T + b);
+ *   y2 = LN2(x_mid);  h = gelu(y2 Wfc1^T + b) (+ stored GELU');  out = x_mid + s_mlp * (h Wfc2^T + b)
+ * s_* = per-sample stochastic-depth factors (dp_attn / dp_mlp, fp32 [rows / rows_per_group], or NULL).  `attn` is the window descriptor
+ * the caller prepared (token tables, bias fragments: lav_attention_build_bias already enqueued on `stream`). */
+typedef struct lav_swin_block_desc {
+    int rows, C, heads, rows_per_group;
+    int qkv_headmajor;
+    float ln_eps;
+    const lav_attn_desc* attn;
+    const float* ln1_gamma; const float* ln1_beta; const void* w_qkv; const float* b_qkv; const void* w_proj; const float* b_proj;
+    const float* ln2_gamma; const float* ln2_beta; const void* w_fc1; const float* b_fc1; const void* w_fc2; const float* b_fc2;
+    const float* dp_attn; const float* dp_mlp;
+    const void* x;                                         /* bf16 (rows, C) */
+    /* outputs / activations kept for the backward (mean*, rstd*, lse, h_pre: NULL in a forward that will not be differentiated) */
+    void* y1; float* mean1; float* rstd1; void* qkv; void* ao; float* lse; void* x_mid; void* y2; float* mean2; float* rstd2;
+    void* h_pre; void* h; void* out;
+} lav_swin_block_desc;
+int lav_swin_block_fwd(void* stream, const lav_swin_block_desc* d);
+
+typedef struct lav_swin_block_bwd_desc {
+    lav_swin_block_desc f;
+    const void* dy;                                        /* bf16 (rows, C) */
+    float alpha_attn, alpha_mlp;                           /* 1 / keep probability of the two stochastic-depth branches (1 without drop-path) */
+    const void* wt_qkv; const void* wt_proj; const void* wt_fc1; const void* wt_fc2;
+    long ldt_qkv, ldt_proj, ldt_fc1, ldt_fc2;
+    float* g_ln1_gamma; float* g_ln1_beta; float* g_w_qkv; float* g_b_qkv; float* g_bias_table; float* g_w_proj; float* g_b_proj;
+    float* g_ln2_gamma; float* g_ln2_beta; float* g_w_fc1; float* g_b_fc1; float* g_w_fc2; float* g_b_fc2;
+    int splits_qkv, splits_proj, splits_fc1, splits_fc2;
+    void* dh; void* d_y2; void* d_mid; void* d_ao; void* dqkv; void* d_y1;     /* temporaries, bf16 */
+    void* dx;                                              /* bf16 (rows, C) */
+} lav_swin_block_bwd_desc;
+/* side_stream as in lav_bert_layer_bwd; the relative-position-bias-table gradient runs there too when lav_attention_bias_split(attn). */
+int lav_swin_block_bwd(void* stream, void* side_stream, const lav_swin_block_bwd_desc* d);
 
 #ifdef __cplusplus
 }

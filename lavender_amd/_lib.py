@@ -54,12 +54,49 @@ class AttnDesc(C.Structure):
                 ("n_types", i32), ("comb", vp), ("combT", vp), ("causal_from", i32), ("qkv_headmajor", i32)]
 
 
+class BertLayerDesc(C.Structure):          # struct lav_bert_layer_desc (stage-level entries)
+    _fields_ = ([(n, i32) for n in ("n_seq", "L", "hidden", "heads", "ffn")] + [(n, f32) for n in ("p_hidden", "p_attn", "ln_eps")] +
+                [(n, u32) for n in ("seed_attn", "seed1", "seed2")] + [("causal_from", i32)] +
+                [(n, vp) for n in ("key_mask", "w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_gamma", "ln1_beta", "w_ff1", "b_ff1", "w_ff2", "b_ff2",
+                                   "ln2_gamma", "ln2_beta", "x", "res_pre", "res_mean", "res_rstd", "res_gamma", "res_beta", "qkv", "cx", "lse",
+                                   "pre1", "mean1", "rstd1", "x1", "h_pre", "h", "pre2", "mean2", "rstd2", "y")])
+
+
+class BertLayerBwdDesc(C.Structure):       # struct lav_bert_layer_bwd_desc
+    _fields_ = ([("f", BertLayerDesc)] + [(n, vp) for n in ("dy", "wt_qkv", "wt_ao", "wt_ff1", "wt_ff2")] +
+                [(n, i64) for n in ("ldt_qkv", "ldt_ao", "ldt_ff1", "ldt_ff2")] +
+                [(n, vp) for n in ("g_w_qkv", "g_b_qkv", "g_w_ao", "g_b_ao", "g_ln1_gamma", "g_ln1_beta", "g_w_ff1", "g_b_ff1", "g_w_ff2", "g_b_ff2",
+                                   "g_ln2_gamma", "g_ln2_beta")] +
+                [(n, i32) for n in ("splits_qkv", "splits_ao", "splits_ff1", "splits_ff2")] +
+                [(n, vp) for n in ("d_pre2", "d_dense2", "dh", "d_x1", "d_pre1", "d_dense1", "d_cx", "dqkv", "dx")])
+
+
+class SwinBlockDesc(C.Structure):          # struct lav_swin_block_desc
+    _fields_ = ([(n, i32) for n in ("rows", "C", "heads", "rows_per_group", "qkv_headmajor")] + [("ln_eps", f32)] +
+                [(n, vp) for n in ("attn", "ln1_gamma", "ln1_beta", "w_qkv", "b_qkv", "w_proj", "b_proj", "ln2_gamma", "ln2_beta", "w_fc1", "b_fc1",
+                                   "w_fc2", "b_fc2", "dp_attn", "dp_mlp", "x", "y1", "mean1", "rstd1", "qkv", "ao", "lse", "x_mid", "y2", "mean2",
+                                   "rstd2", "h_pre", "h", "out")])
+
+
+class SwinBlockBwdDesc(C.Structure):       # struct lav_swin_block_bwd_desc
+    _fields_ = ([("f", SwinBlockDesc), ("dy", vp), ("alpha_attn", f32), ("alpha_mlp", f32)] +
+                [(n, vp) for n in ("wt_qkv", "wt_proj", "wt_fc1", "wt_fc2")] + [(n, i64) for n in ("ldt_qkv", "ldt_proj", "ldt_fc1", "ldt_fc2")] +
+                [(n, vp) for n in ("g_ln1_gamma", "g_ln1_beta", "g_w_qkv", "g_b_qkv", "g_bias_table", "g_w_proj", "g_b_proj", "g_ln2_gamma", "g_ln2_beta",
+                                   "g_w_fc1", "g_b_fc1", "g_w_fc2", "g_b_fc2")] +
+                [(n, i32) for n in ("splits_qkv", "splits_proj", "splits_fc1", "splits_fc2")] +
+                [(n, vp) for n in ("dh", "d_y2", "d_mid", "d_ao", "dqkv", "d_y1", "dx")])
+
+
 P = C.POINTER
 _SIGS = {
     "lav_last_error": (C.c_char_p, []),
     "lav_abi_version": (i32, []),
     "lav_gemm_bf16": (i32, [vp, i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, P(GemmEpilogue), i32]),
     "lav_gemm_select": (i32, [i32, i32]),
+    "lav_bert_layer_fwd": (i32, [vp, P(BertLayerDesc)]),
+    "lav_bert_layer_bwd": (i32, [vp, vp, P(BertLayerBwdDesc)]),
+    "lav_swin_block_fwd": (i32, [vp, P(SwinBlockDesc)]),
+    "lav_swin_block_bwd": (i32, [vp, vp, P(SwinBlockBwdDesc)]),
     "lav_layernorm_fwd": (i32, [vp, i32, i32, vp, i64, P(LnGather), vp, vp, f32, vp, i64, vp, vp, P(LnF32)]),
     "lav_layernorm_bwd": (i32, [vp, i32, i32, vp, i64, vp, i64, P(LnGather), vp, vp, vp, vp, i64, vp, i64, vp, vp,
                                 P(LnBwdExtra)]),

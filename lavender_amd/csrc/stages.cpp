@@ -1,0 +1,246 @@
+// Stage-level entry points (host side only): one C call enqueues every kernel of a fusion-encoder layer, forward or backward, by calling
+// the per-kernel entries of this library in the order and with the arguments lavender_amd/engine.py:BertLayerFn uses -- same kernels,
+// same bits; what goes away is ~20 Python -> ctypes transitions per stage (13 us each against ~1.5 us for a call from here).
+// Reference: HF BertLayer as driven by LAVENDER_Base.go_cross (model.py:239-243); the backward is its autograd transcript.
+#include "common.h"
+#include <math.h>
+#include <string.h>
+#include "../../include/lavender_hip.h"
+
+#define LAV_TRY(call) do { const int rc_ = (call); if (rc_ != LAV_OK) return rc_; } while (0)
+
+static lav_gemm_epilogue epi0() {
+    lav_gemm_epilogue e;
+    memset(&e, 0, sizeof(e));
+    e.alpha = 1.f; e.rows_per_group = 1; e.k_rows_per_group = 1;
+    return e;
+}
+
+static void seq_desc(const lav_bert_layer_desc* d, lav_attn_desc& a) {
+    memset(&a, 0, sizeof(a));
+    a.mode = 1; a.heads = d->heads; a.head_dim = d->hidden / d->heads;
+    a.n_seq = d->n_seq; a.L = d->L; a.key_mask = d->key_mask;
+    a.dropout_p = d->p_attn; a.seed = d->seed_attn;
+    a.scale = (float)pow((double)a.head_dim, -0.5);          // as the host layer computes it (double, then narrowed)
+    a.causal_from = d->causal_from;
+}
+
+extern "C" int lav_bert_layer_fwd(void* stream, const lav_bert_layer_desc* d) {
+    LAV_REQUIRE(d, "lav_bert_layer_fwd: null descriptor");
+    LAV_REQUIRE(d->n_seq > 0 && d->L > 0 && d->hidden > 0 && d->heads > 0 && d->ffn > 0 && d->hidden % d->heads == 0,
+                "lav_bert_layer_fwd: bad dimensions n_seq=%d L=%d hidden=%d heads=%d ffn=%d", d->n_seq, d->L, d->hidden, d->heads, d->ffn);
+    LAV_REQUIRE(d->x && d->w_qkv && d->w_ao && d->w_ff1 && d->w_ff2 && d->qkv && d->cx && d->pre1 && d->x1 && d->h && d->pre2 && d->y &&
+                d->mean1 && d->rstd1, "lav_bert_layer_fwd: null buffer");
+    const int R = d->n_seq * d->L, H = d->hidden, F = d->ffn;
+    const bool resln = d->res_pre != nullptr;
+    LAV_REQUIRE(!resln || (d->res_mean && d->res_rstd && d->res_gamma && d->res_beta), "lav_bert_layer_fwd: res_pre without its LayerNorm statistics");
+    // qkv = x Wqkv^T + b
+    {
+        lav_gemm_epilogue e = epi0();
+        e.bias = d->b_qkv;
+        LAV_TRY(lav_gemm_bf16(stream, 0, R, 3 * H, H, d->x, H, d->w_qkv, H, d->qkv, 3 * H, &e, 1));
+    }
+    // cx = softmax(q k^T / sqrt(hd) + mask) (dropout) v
+    {
+        lav_attn_desc a;
+        seq_desc(d, a);
+        LAV_TRY(lav_attention_fwd(stream, &a, d->qkv, d->cx, d->lse));
+    }
+    // pre1 = res + dropout(cx Wao^T + b), fp32
+    {
+        lav_gemm_epilogue e = epi0();
+        e.bias = d->b_ao; e.dropout_p = d->p_hidden; e.seed = d->seed1; e.out_mode = 1;
+        if (resln) {
+            e.residual = d->res_pre; e.ldr = H; e.residual_f32 = 1;
+            e.res_ln_mean = d->res_mean; e.res_ln_rstd = d->res_rstd; e.res_ln_gamma = d->res_gamma; e.res_ln_beta = d->res_beta;
+        } else { e.residual = d->x; e.ldr = H; e.residual_f32 = 0; }
+        LAV_TRY(lav_gemm_bf16(stream, 0, R, H, H, d->cx, H, d->w_ao, H, d->pre1, H, &e, 1));
+    }
+    lav_ln_f32 f32io; f32io.x_f32 = 1; f32io.y32 = nullptr; f32io.ldy32 = 0;
+    LAV_TRY(lav_layernorm_fwd(stream, R, H, d->pre1, H, nullptr, d->ln1_gamma, d->ln1_beta, d->ln_eps, d->x1, H, d->mean1, d->rstd1, &f32io));
+    // h = gelu(x1 Wff1^T + b), GELU' kept for the backward
+    {
+        lav_gemm_epilogue e = epi0();
+        e.bias = d->b_ff1; e.act = 1; e.preact = d->h_pre; e.ldp = F; e.preact_is_grad = d->h_pre ? 1 : 0;
+        LAV_TRY(lav_gemm_bf16(stream, 0, R, F, H, d->x1, H, d->w_ff1, H, d->h, F, &e, 1));
+    }
+    // pre2 = LN1(pre1) + dropout(h Wff2^T + b), fp32: the LayerNorm output is recomputed from the saved pre-LN rows in the epilogue
+    {
+        lav_gemm_epilogue e = epi0();
+        e.bias = d->b_ff2; e.dropout_p = d->p_hidden; e.seed = d->seed2; e.out_mode = 1;
+        e.residual = d->pre1; e.ldr = H; e.residual_f32 = 1;
+        e.res_ln_mean = d->mean1; e.res_ln_rstd = d->rstd1; e.res_ln_gamma = d->ln1_gamma; e.res_ln_beta = d->ln1_beta;
+        LAV_TRY(lav_gemm_bf16(stream, 0, R, H, F, d->h, F, d->w_ff2, F, d->pre2, H, &e, 1));
+    }
+    LAV_TRY(lav_layernorm_fwd(stream, R, H, d->pre2, H, nullptr, d->ln2_gamma, d->ln2_beta, d->ln_eps, d->y, H, d->mean2, d->rstd2, &f32io));
+    return LAV_OK;
+}
+
+// main -> side ordering: the side stream waits for everything enqueued on the main stream so far
+static hipEvent_t g_fork[32];
+static int g_fork_n = 0, g_fork_next = 0;
+static int fork_to(hipStream_t main_s, hipStream_t side_s) {
+    if (side_s == main_s) return LAV_OK;
+    if (g_fork_n == 0) {
+        for (int i = 0; i < 32; ++i)
+            if (hipEventCreateWithFlags(&g_fork[i], hipEventDisableTiming) != hipSuccess) { lav_set_error("stage entry: hipEventCreate failed"); return LAV_E_LAUNCH; }
+        g_fork_n = 32;
+    }
+    hipEvent_t ev = g_fork[g_fork_next];
+    g_fork_next = (g_fork_next + 1) % g_fork_n;
+    if (hipEventRecord(ev, main_s) != hipSuccess || hipStreamWaitEvent(side_s, ev, 0) != hipSuccess) {
+        lav_set_error("stage entry: event record / wait failed"); (void)hipGetLastError(); return LAV_E_LAUNCH;
+    }
+    return LAV_OK;
+}
+
+static int dw_gemm(hipStream_t main_s, hipStream_t side_s, int M, int N, int K, const void* A, const void* B, float* out, int splits, float* rowsum) {
+    LAV_TRY(fork_to(main_s, side_s));
+    lav_gemm_epilogue e = epi0();
+    e.out_mode = 2; e.rowsum_a = rowsum;
+    return lav_gemm_bf16(side_s, 2, M, N, K, A, M, B, N, out, N, &e, splits);
+}
+
+extern "C" int lav_bert_layer_bwd(void* stream, void* side_stream, const lav_bert_layer_bwd_desc* b) {
+    LAV_REQUIRE(b, "lav_bert_layer_bwd: null descriptor");
+    const lav_bert_layer_desc* d = &b->f;
+    LAV_REQUIRE(d->n_seq > 0 && d->L > 0 && d->hidden > 0 && d->heads > 0 && d->ffn > 0, "lav_bert_layer_bwd: bad dimensions");
+    LAV_REQUIRE(b->dy && d->lse && d->h_pre && b->d_pre2 && b->d_dense2 && b->dh && b->d_x1 && b->d_pre1 && b->d_dense1 && b->d_cx && b->dqkv && b->dx &&
+                b->wt_qkv && b->wt_ao && b->wt_ff1 && b->wt_ff2, "lav_bert_layer_bwd: null buffer (the forward must have kept lse and GELU')");
+    hipStream_t ms = (hipStream_t)stream, ss = side_stream ? (hipStream_t)side_stream : ms;
+    const int R = d->n_seq * d->L, H = d->hidden, F = d->ffn;
+    // y = LN2(pre2), pre2 = x1 + dropout(dense(h)): d_pre2 (residual branch) and d_dense2 = dropout'(d_pre2) (+ its column sums = bias gradient)
+    {
+        lav_ln_bwd_extra ex; memset(&ex, 0, sizeof(ex));
+        ex.dx2 = b->d_dense2; ex.lddx2 = H; ex.rows_per_group = 1; ex.dropout_p = d->p_hidden; ex.seed = d->seed2; ex.colsum = b->g_b_ff2; ex.x_f32 = 1;
+        LAV_TRY(lav_layernorm_bwd(stream, R, H, b->dy, H, d->pre2, H, nullptr, d->ln2_gamma, d->mean2, d->rstd2, nullptr, 0, b->d_pre2, H,
+                                  b->g_ln2_gamma, b->g_ln2_beta, &ex));
+    }
+    LAV_TRY(dw_gemm(ms, ss, H, F, R, b->d_dense2, d->h, b->g_w_ff2, b->splits_ff2, nullptr));
+    {
+        lav_gemm_epilogue e = epi0();
+        e.gelu_in = d->h_pre; e.ldg = F; e.gelu_in_is_grad = 1; e.colsum = b->g_b_ff1;
+        LAV_TRY(lav_gemm_bf16(stream, 0, R, F, H, b->d_dense2, H, b->wt_ff2, b->ldt_ff2, b->dh, F, &e, 1));
+    }
+    LAV_TRY(dw_gemm(ms, ss, F, H, R, b->dh, d->x1, b->g_w_ff1, b->splits_ff1, nullptr));
+    {
+        lav_gemm_epilogue e = epi0();
+        e.residual = b->d_pre2; e.ldr = H;
+        LAV_TRY(lav_gemm_bf16(stream, 0, R, H, F, b->dh, F, b->wt_ff1, b->ldt_ff1, b->d_x1, H, &e, 1));
+    }
+    // x1 = LN1(pre1), pre1 = x + dropout(dense(cx))
+    {
+        lav_ln_bwd_extra ex; memset(&ex, 0, sizeof(ex));
+        ex.dx2 = b->d_dense1; ex.lddx2 = H; ex.rows_per_group = 1; ex.dropout_p = d->p_hidden; ex.seed = d->seed1; ex.colsum = b->g_b_ao; ex.x_f32 = 1;
+        LAV_TRY(lav_layernorm_bwd(stream, R, H, b->d_x1, H, d->pre1, H, nullptr, d->ln1_gamma, d->mean1, d->rstd1, nullptr, 0, b->d_pre1, H,
+                                  b->g_ln1_gamma, b->g_ln1_beta, &ex));
+    }
+    LAV_TRY(dw_gemm(ms, ss, H, H, R, b->d_dense1, d->cx, b->g_w_ao, b->splits_ao, nullptr));
+    {
+        lav_gemm_epilogue e = epi0();
+        LAV_TRY(lav_gemm_bf16(stream, 0, R, H, H, b->d_dense1, H, b->wt_ao, b->ldt_ao, b->d_cx, H, &e, 1));
+    }
+    {
+        lav_attn_desc a;
+        seq_desc(d, a);
+        LAV_TRY(lav_attention_bwd(stream, &a, d->qkv, d->cx, b->d_cx, d->lse, b->dqkv, nullptr));
+    }
+    LAV_TRY(dw_gemm(ms, ss, 3 * H, H, R, b->dqkv, d->x, b->g_w_qkv, b->splits_qkv, b->g_b_qkv));
+    {
+        lav_gemm_epilogue e = epi0();
+        e.residual = b->d_pre1; e.ldr = H;
+        LAV_TRY(lav_gemm_bf16(stream, 0, R, H, 3 * H, b->dqkv, 3 * H, b->wt_qkv, b->ldt_qkv, b->dx, H, &e, 1));
+    }
+    return LAV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// SwinTransformerBlock3D (video_swin.py:204-261), engine.SwinBlockFn's launch sequence for token grids that are window multiples
+// ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" int lav_swin_block_fwd(void* stream, const lav_swin_block_desc* d) {
+    LAV_REQUIRE(d && d->attn, "lav_swin_block_fwd: null descriptor");
+    LAV_REQUIRE(d->rows > 0 && d->C > 0 && d->heads > 0 && d->C % d->heads == 0 && d->rows_per_group > 0, "lav_swin_block_fwd: bad dimensions rows=%d C=%d heads=%d",
+                d->rows, d->C, d->heads);
+    LAV_REQUIRE(d->x && d->y1 && d->qkv && d->ao && d->x_mid && d->y2 && d->h && d->out && d->w_qkv && d->w_proj && d->w_fc1 && d->w_fc2,
+                "lav_swin_block_fwd: null buffer");
+    const int M = d->rows, C = d->C;
+    LAV_TRY(lav_layernorm_fwd(stream, M, C, d->x, C, nullptr, d->ln1_gamma, d->ln1_beta, d->ln_eps, d->y1, C, d->mean1, d->rstd1, nullptr));
+    {
+        lav_gemm_epilogue e = epi0();
+        e.bias = d->b_qkv;
+        if (d->qkv_headmajor) { e.hm_heads = d->heads; e.hm_head_dim = C / d->heads; e.hm_rows = M; }
+        LAV_TRY(lav_gemm_bf16(stream, 0, M, 3 * C, C, d->y1, C, d->w_qkv, C, d->qkv, 3 * C, &e, 1));
+    }
+    LAV_TRY(lav_attention_fwd(stream, d->attn, d->qkv, d->ao, d->lse));
+    {
+        lav_gemm_epilogue e = epi0();
+        e.bias = d->b_proj; e.row_scale = d->dp_attn; e.rows_per_group = d->rows_per_group; e.residual = d->x; e.ldr = C;
+        LAV_TRY(lav_gemm_bf16(stream, 0, M, C, C, d->ao, C, d->w_proj, C, d->x_mid, C, &e, 1));
+    }
+    LAV_TRY(lav_layernorm_fwd(stream, M, C, d->x_mid, C, nullptr, d->ln2_gamma, d->ln2_beta, d->ln_eps, d->y2, C, d->mean2, d->rstd2, nullptr));
+    {
+        lav_gemm_epilogue e = epi0();
+        e.bias = d->b_fc1; e.act = 1; e.preact = d->h_pre; e.ldp = 4 * C; e.preact_is_grad = 1;
+        LAV_TRY(lav_gemm_bf16(stream, 0, M, 4 * C, C, d->y2, C, d->w_fc1, C, d->h, 4 * C, &e, 1));
+    }
+    {
+        lav_gemm_epilogue e = epi0();
+        e.bias = d->b_fc2; e.row_scale = d->dp_mlp; e.rows_per_group = d->rows_per_group; e.residual = d->x_mid; e.ldr = C;
+        LAV_TRY(lav_gemm_bf16(stream, 0, M, C, 4 * C, d->h, 4 * C, d->w_fc2, 4 * C, d->out, C, &e, 1));
+    }
+    return LAV_OK;
+}
+
+static int dw_gemm_keep(hipStream_t main_s, hipStream_t side_s, int M, int N, int K, const void* A, const void* B, float* out, int splits, float* rowsum,
+                        const float* keep, int rows_per_group, float alpha) {
+    LAV_TRY(fork_to(main_s, side_s));
+    lav_gemm_epilogue e = epi0();
+    e.out_mode = 2; e.rowsum_a = rowsum; e.k_keep = keep; e.k_rows_per_group = keep ? rows_per_group : 1; e.alpha = keep ? alpha : 1.f;
+    return lav_gemm_bf16(side_s, 2, M, N, K, A, M, B, N, out, N, &e, splits);
+}
+
+extern "C" int lav_swin_block_bwd(void* stream, void* side_stream, const lav_swin_block_bwd_desc* b) {
+    LAV_REQUIRE(b && b->f.attn, "lav_swin_block_bwd: null descriptor");
+    const lav_swin_block_desc* d = &b->f;
+    LAV_REQUIRE(b->dy && d->lse && d->h_pre && d->mean1 && d->rstd1 && d->mean2 && d->rstd2 && b->dh && b->d_y2 && b->d_mid && b->d_ao && b->dqkv && b->d_y1 &&
+                b->dx && b->wt_qkv && b->wt_proj && b->wt_fc1 && b->wt_fc2, "lav_swin_block_bwd: null buffer (the forward must have kept lse, GELU' and the LayerNorm statistics)");
+    hipStream_t ms = (hipStream_t)stream, ss = side_stream ? (hipStream_t)side_stream : ms;
+    const int M = d->rows, C = d->C, rpg = d->rows_per_group;
+    // MLP branch: out = x_mid + s * fc2(gelu(fc1(LN2(x_mid))))
+    LAV_TRY(dw_gemm_keep(ms, ss, C, 4 * C, M, b->dy, d->h, b->g_w_fc2, b->splits_fc2, b->g_b_fc2, d->dp_mlp, rpg, b->alpha_mlp));
+    {
+        lav_gemm_epilogue e = epi0();
+        e.gelu_in = d->h_pre; e.ldg = 4 * C; e.gelu_in_is_grad = 1; e.row_scale = d->dp_mlp; e.rows_per_group = rpg; e.colsum = b->g_b_fc1;
+        LAV_TRY(lav_gemm_bf16(stream, 0, M, 4 * C, C, b->dy, C, b->wt_fc2, b->ldt_fc2, b->dh, 4 * C, &e, 1));
+    }
+    LAV_TRY(dw_gemm(ms, ss, 4 * C, C, M, b->dh, d->y2, b->g_w_fc1, b->splits_fc1, nullptr));
+    {
+        lav_gemm_epilogue e = epi0();
+        LAV_TRY(lav_gemm_bf16(stream, 0, M, C, 4 * C, b->dh, 4 * C, b->wt_fc1, b->ldt_fc1, b->d_y2, C, &e, 1));
+    }
+    LAV_TRY(lav_layernorm_bwd(stream, M, C, b->d_y2, C, d->x_mid, C, nullptr, d->ln2_gamma, d->mean2, d->rstd2, b->dy, C, b->d_mid, C,
+                              b->g_ln2_gamma, b->g_ln2_beta, nullptr));
+    // attention branch: x_mid = x + s * proj(attn(qkv(LN1(x))))
+    LAV_TRY(dw_gemm_keep(ms, ss, C, C, M, b->d_mid, d->ao, b->g_w_proj, b->splits_proj, b->g_b_proj, d->dp_attn, rpg, b->alpha_attn));
+    {
+        lav_gemm_epilogue e = epi0();
+        e.row_scale = d->dp_attn; e.rows_per_group = rpg;
+        LAV_TRY(lav_gemm_bf16(stream, 0, M, C, C, b->d_mid, C, b->wt_proj, b->ldt_proj, b->d_ao, C, &e, 1));
+    }
+    if (ss != ms && lav_attention_bias_split(d->attn)) {
+        // the relative-position-bias gradient is a parameter gradient: its own launch on the weight-gradient stream
+        LAV_TRY(lav_attention_bwd(stream, d->attn, d->qkv, d->ao, b->d_ao, d->lse, b->dqkv, nullptr));
+        LAV_TRY(fork_to(ms, ss));
+        LAV_TRY(lav_attention_bwd_bias(ss, d->attn, d->qkv, b->d_ao, d->lse, b->g_bias_table));
+    } else {
+        LAV_TRY(lav_attention_bwd(stream, d->attn, d->qkv, d->ao, b->d_ao, d->lse, b->dqkv, b->g_bias_table));
+    }
+    LAV_TRY(dw_gemm(ms, ss, 3 * C, C, M, b->dqkv, d->y1, b->g_w_qkv, b->splits_qkv, b->g_b_qkv));
+    {
+        lav_gemm_epilogue e = epi0();
+        LAV_TRY(lav_gemm_bf16(stream, 0, M, C, 3 * C, b->dqkv, 3 * C, b->wt_qkv, b->ldt_qkv, b->d_y1, C, &e, 1));
+    }
+    LAV_TRY(lav_layernorm_bwd(stream, M, C, b->d_y1, C, d->x, C, nullptr, d->ln1_gamma, d->mean1, d->rstd1, b->d_mid, C, b->dx, C,
+                              b->g_ln1_gamma, b->g_ln1_beta, nullptr));
+    return LAV_OK;
+}

@@ -62,6 +62,11 @@ RESLN = STREAM32 and os.environ.get("LAV_RESLN", "1") != "0"
 # so that a window's operand pieces are whole 128-byte lines instead of 64-byte halves of the (rows, 3C) rows.  Only the attention
 # kernels read qkv (its gradient dqkv stays row-major: it is a GEMM operand).  LAV_QKV_HEADMAJOR=0 restores the row-major layout.
 QKV_HEADMAJOR = os.environ.get("LAV_QKV_HEADMAJOR", "1") != "0"
+# Fusion-encoder layers through the stage-level C entries (lav_bert_layer_fwd / _bwd, csrc/stages.cpp): one host -> C transition per
+# layer pass instead of 7 (forward) / 15 (backward); the same kernels with the same arguments, bit-identical results.  Applies to the
+# default configuration (fp32 residual stream with the recomputed-LayerNorm residual, bf16 GELU') of every layer that does not read its
+# input through the pair map.  LAV_STAGE_C=0 restores the per-kernel path.
+STAGE_C = os.environ.get("LAV_STAGE_C", "1") != "0"
 
 
 def dw_stream(device):
@@ -178,6 +183,8 @@ class SwinBlockFn(torch.autograd.Function):
         y1, mean1, rstd1 = K.layernorm_fwd(x, M, C, blk.norm1.weight.data, blk.norm1.bias.data, 1e-5, want_stats=keep)
         win, sh, cfg = geo["window"], geo["shift"], geo["cfg_window"]
         pad = pad_maps(x.device, B, (D, H, Wd), win)
+        if STAGE_C and pad is None and _GQ == 1 and x.is_contiguous():
+            return SwinBlockFn._forward_c(ctx, x, blk, geo, dp_attn, dp_mlp, keep)
         if pad is not None:
             # zero rows AFTER norm1 up to window multiples (video_swin.py:211-215): the qkv GEMM then gives the padded tokens
             # q = k = v = bias, exactly what Linear(0) is in the reference; they attend and are attended to (no mask)
@@ -217,7 +224,94 @@ class SwinBlockFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    def _block_consts(blk, arena):
+        c = blk.__dict__.get("_lav_stage_consts")
+        if c is not None and c[0] is arena:
+            return c[1]
+        a, mlp = blk.attn, blk.mlp
+        dp = lambda t: t.data_ptr()
+        params = (dp(blk.norm1.weight.data), dp(blk.norm1.bias.data), dp(W16(a.qkv.weight)), dp(a.qkv.bias.data), dp(W16(a.proj.weight)),
+                  dp(a.proj.bias.data), dp(blk.norm2.weight.data), dp(blk.norm2.bias.data), dp(W16(mlp.fc1.weight)), dp(mlp.fc1.bias.data),
+                  dp(W16(mlp.fc2.weight)), dp(mlp.fc2.bias.data))
+        wt = (W16T(a.qkv.weight), W16T(a.proj.weight), W16T(mlp.fc1.weight), W16T(mlp.fc2.weight))
+        bwd = tuple(dp(t) for t in wt) + tuple(K._ld(t) for t in wt) + (
+            dp(G(blk.norm1.weight)), dp(G(blk.norm1.bias)), dp(G(a.qkv.weight)), dp(G(a.qkv.bias)), dp(G(a.relative_position_bias_table)),
+            dp(G(a.proj.weight)), dp(G(a.proj.bias)), dp(G(blk.norm2.weight)), dp(G(blk.norm2.bias)), dp(G(mlp.fc1.weight)), dp(G(mlp.fc1.bias)),
+            dp(G(mlp.fc2.weight)), dp(G(mlp.fc2.bias)))
+        consts = dict(params=params, bwd=bwd)
+        blk.__dict__["_lav_stage_consts"] = (arena, consts)
+        return consts
+
+    @staticmethod
+    def _forward_c(ctx, x, blk, geo, dp_attn, dp_mlp, keep):
+        """the seven launches of the block (grid a multiple of the window) through ONE call of lav_swin_block_fwd"""
+        import ctypes as C
+        M, Cn = x.shape
+        heads = blk.num_heads
+        B, D, H, Wd = geo["B"], geo["D"], geo["H"], geo["W"]
+        rpg = M // B
+        a = blk.attn
+        win, sh, cfg = geo["window"], geo["shift"], geo["cfg_window"]
+        c = SwinBlockFn._block_consts(blk, geo.get("arena"))
+        hm = QKV_HEADMAJOR and Cn // heads == 32 and win[0] * win[1] * win[2] <= 256
+        att = K.Attn(0, heads, Cn // heads, B=B, D=D, H=H, W=Wd, wd=win[0], wh=win[1], ww=win[2], sd=sh[0], sh=sh[1],
+                     sw=sh[2], cfg_wd=cfg[0], cfg_wh=cfg[1], cfg_ww=cfg[2], bias_table=a.relative_position_bias_table.data,
+                     qkv_headmajor=int(hm))
+        dev, f32 = x.device, torch.float32
+        e = torch.empty
+        y1, ao, x_mid, y2, out = (e((M, Cn), dtype=bf16, device=dev) for _ in range(5))
+        qkv, h = e((M, 3 * Cn), dtype=bf16, device=dev), e((M, 4 * Cn), dtype=bf16, device=dev)
+        st = lse = h_pre = None
+        p_st = 0
+        if keep:
+            st = e((4, M), dtype=f32, device=dev)           # mean1, rstd1, mean2, rstd2
+            p_st = st.data_ptr()
+            lse = e(att.lse_elems(), dtype=f32, device=dev)
+            h_pre = e((M, 4 * Cn), dtype=bf16, device=dev)
+        fields = (M, Cn, heads, rpg, int(hm), 1e-5, C.addressof(att.d)) + c["params"] + (
+            K._dp(dp_attn), K._dp(dp_mlp), x.data_ptr(), y1.data_ptr(), p_st, p_st + 4 * M if keep else 0, qkv.data_ptr(), ao.data_ptr(), K._dp(lse),
+            x_mid.data_ptr(), y2.data_ptr(), p_st + 8 * M if keep else 0, p_st + 12 * M if keep else 0, K._dp(h_pre), h.data_ptr(), out.data_ptr())
+        K.swin_block_fwd(fields)
+        if keep:
+            ctx.blk, ctx.att, ctx.rpg = blk, att, rpg
+            ctx.notify = geo.get("notify")
+            ctx.arena = geo.get("arena")
+            ctx.keep_attn = float(blk.keep_prob) if dp_attn is not None else 1.0
+            ctx.has_dp = dp_attn is not None
+            ctx.pad = None
+            ctx.c_stage, ctx.c_fields, ctx.c_consts = True, fields, c
+            ctx.save_for_backward(x, y1, st, qkv, ao, lse, x_mid, y2, h_pre, h,
+                                  dp_attn if dp_attn is not None else x.new_empty(0), dp_mlp if dp_mlp is not None else x.new_empty(0))
+        return out
+
+    @staticmethod
+    def _backward_c(ctx, dy):
+        blk, att = ctx.blk, ctx.att
+        x, y1, st, qkv, ao, lse, x_mid, y2, h_pre, h, dp_attn, dp_mlp = ctx.saved_tensors
+        M, Cn = x.shape
+        dev = x.device
+        e = torch.empty
+        d_y2, d_mid, d_ao, d_y1, dx = (e((M, Cn), dtype=bf16, device=dev) for _ in range(5))
+        dh, dqkv = e((M, 4 * Cn), dtype=bf16, device=dev), e((M, 3 * Cn), dtype=bf16, device=dev)
+        alpha = 1.0 / ctx.keep_attn
+        has_dp = ctx.has_dp
+        splits = (K.splits_for(3 * Cn, Cn, M), K.splits_for(Cn, Cn, M, has_dp), K.splits_for(4 * Cn, Cn, M), K.splits_for(Cn, 4 * Cn, M, has_dp))
+        b = ctx.c_consts["bwd"]
+        fields = ctx.c_fields + (dy.data_ptr(), alpha, alpha) + b[:21] + splits + (
+            dh.data_ptr(), d_y2.data_ptr(), d_mid.data_ptr(), d_ao.data_ptr(), dqkv.data_ptr(), d_y1.data_ptr(), dx.data_ptr())
+        side = dw_stream(dev) if _DW_SIDE else None
+        K.swin_block_bwd(fields, side.cuda_stream if side is not None else None)
+        if side is not None:
+            for t in (dy, h, dh, y2, d_mid, ao, dqkv, y1, qkv, d_ao, lse) + ((dp_attn, dp_mlp) if has_dp else ()):
+                t.record_stream(side)
+        if ctx.notify and ctx.arena is not None:
+            ctx.arena.notify(ctx.notify)
+        return None, dx, None, None, None, None
+
+    @staticmethod
     def backward(ctx, dy):
+        if getattr(ctx, "c_stage", False):
+            return SwinBlockFn._backward_c(ctx, dy.contiguous())
         blk, att, rpg = ctx.blk, ctx.att, ctx.rpg
         a, mlp = blk.attn, blk.mlp
         x, y1, mean1, rstd1, qkv, ao, lse, x_mid, y2, mean2, rstd2, h_pre, h, dp_attn, dp_mlp, ao_p = ctx.saved_tensors
@@ -514,6 +608,9 @@ class BertLayerFn(torch.autograd.Function):
         wqkv16, _, _ = arena.fused_view(att_m.query.weight, 3 * Hd)
         _, _, bqkv = arena.fused_view(att_m.query.bias, 3 * Hd)
         keep = _keep(ctx)
+        resln_t = x32 if isinstance(x32, tuple) else None
+        if STAGE_C and RESLN and _GQ == 1 and pair is None and (x32 is None or resln_t is not None):
+            return BertLayerFn._forward_c(ctx, x, resln_t, layer, key_mask, n, L, p_hidden, p_attn, want32, causal_from, keep, wqkv16, bqkv)
         qkv = K.gemm(0, x, wqkv16, R, 3 * Hd, Hd, bias=bqkv, a_rowmap=rowmap)
         s_att, s1, s2 = K.next_seed(), K.next_seed(), K.next_seed()
         att = K.Attn(1, heads, Hd // heads, n_seq=n, L=L, key_mask=key_mask, dropout_p=p_attn, seed=s_att, causal_from=int(causal_from))
@@ -549,9 +646,99 @@ class BertLayerFn(torch.autograd.Function):
         return y, y32
 
     @staticmethod
+    def _layer_consts(layer, arena, wqkv16, bqkv):
+        """device addresses of the layer's parameters / gradient accumulators / transposed copies (arena views: fixed for the arena's life)"""
+        c = layer.__dict__.get("_lav_stage_consts")
+        if c is not None and c[0] is arena:
+            return c[1]
+        att_m, ao, inter, outp = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+        Hd = wqkv16.shape[1]
+        _, gwqkv, _ = arena.fused_view(att_m.query.weight, 3 * Hd)
+        _, gbqkv, _ = arena.fused_view(att_m.query.bias, 3 * Hd)
+        dp = lambda t: t.data_ptr()
+        params = (dp(wqkv16), dp(bqkv), dp(W16(ao.dense.weight)), dp(ao.dense.bias.data), dp(ao.LayerNorm.weight.data), dp(ao.LayerNorm.bias.data),
+                  dp(W16(inter.dense.weight)), dp(inter.dense.bias.data), dp(W16(outp.dense.weight)), dp(outp.dense.bias.data),
+                  dp(outp.LayerNorm.weight.data), dp(outp.LayerNorm.bias.data))
+        wt = (W16T(att_m.query.weight), W16T(ao.dense.weight), W16T(inter.dense.weight), W16T(outp.dense.weight))
+        bwd = tuple(dp(t) for t in wt) + tuple(K._ld(t) for t in wt) + (
+            dp(gwqkv), dp(gbqkv), dp(G(ao.dense.weight)), dp(G(ao.dense.bias)), dp(G(ao.LayerNorm.weight)), dp(G(ao.LayerNorm.bias)),
+            dp(G(inter.dense.weight)), dp(G(inter.dense.bias)), dp(G(outp.dense.weight)), dp(G(outp.dense.bias)),
+            dp(G(outp.LayerNorm.weight)), dp(G(outp.LayerNorm.bias)))
+        consts = dict(params=params, bwd=bwd, eps=float(ao.LayerNorm.eps), ffn=inter.dense.weight.shape[0], heads=layer.num_heads)
+        layer.__dict__["_lav_stage_consts"] = (arena, consts)
+        return consts
+
+    @staticmethod
+    def _forward_c(ctx, x, resln_t, layer, key_mask, n, L, p_hidden, p_attn, want32, causal_from, keep, wqkv16, bqkv):
+        """the same seven launches as the per-kernel path below, enqueued by ONE call of lav_bert_layer_fwd"""
+        Hd, R = x.shape[1], n * L
+        assert x.shape[0] == R and x.is_contiguous()
+        dev, f32 = x.device, torch.float32
+        c = BertLayerFn._layer_consts(layer, layer._arena(), wqkv16, bqkv)
+        F = c["ffn"]
+        s_att, s1, s2 = K.next_seed(), K.next_seed(), K.next_seed()
+        e = torch.empty
+        qkv, cx, x1, h, y = e((R, 3 * Hd), dtype=bf16, device=dev), e((R, Hd), dtype=bf16, device=dev), e((R, Hd), dtype=bf16, device=dev), \
+            e((R, F), dtype=bf16, device=dev), e((R, Hd), dtype=bf16, device=dev)
+        pre1, pre2 = e((R, Hd), dtype=f32, device=dev), e((R, Hd), dtype=f32, device=dev)
+        st1, st2 = e((2, R), dtype=f32, device=dev), e((2, R), dtype=f32, device=dev)          # (mean, rstd) of the two LayerNorms
+        lse = h_pre = None
+        if keep:
+            att = K.Attn(1, c["heads"], Hd // c["heads"], n_seq=n, L=L, key_mask=key_mask, dropout_p=p_attn, seed=s_att, causal_from=int(causal_from))
+            lse = e(att.lse_elems(), dtype=f32, device=dev)
+            h_pre = e((R, F), dtype=bf16, device=dev)
+        if resln_t is not None:
+            res = tuple(t.data_ptr() for t in resln_t)         # (pre, mean, rstd, gamma, beta) of the producing LayerNorm
+        else:
+            res = (0, 0, 0, 0, 0)
+        p1, p2 = st1.data_ptr(), st2.data_ptr()
+        fields = (n, L, Hd, c["heads"], F, float(p_hidden), float(p_attn), c["eps"], s_att, s1, s2, int(causal_from),
+                  K._dp(key_mask)) + c["params"] + (x.data_ptr(),) + res + (
+                  qkv.data_ptr(), cx.data_ptr(), K._dp(lse), pre1.data_ptr(), p1, p1 + 4 * R, x1.data_ptr(), K._dp(h_pre), h.data_ptr(),
+                  pre2.data_ptr(), p2, p2 + 4 * R, y.data_ptr())
+        K.bert_layer_fwd(fields)
+        mean2, rstd2 = st2[0], st2[1]
+        if keep:
+            ctx.layer, ctx.seeds, ctx.p = layer, (s1, s2), p_hidden
+            ctx.pair = None
+            ctx.c_fields = fields                              # device addresses stay valid: every buffer is a saved tensor below
+            ctx.c_stage = True
+            ctx.save_for_backward(x, qkv, cx, lse, pre1, st1, x1, h_pre, h, pre2, st2, key_mask if key_mask is not None else x.new_empty(0),
+                                  *(resln_t[:3] if resln_t is not None else ()))
+        if want32:
+            ctx.mark_non_differentiable(pre2, mean2, rstd2)
+            return y, pre2, mean2, rstd2
+        return y, None
+
+    @staticmethod
+    def _backward_c(ctx, dy):
+        layer = ctx.layer
+        x, qkv, cx, lse, pre1, st1, x1, h_pre, h, pre2, st2 = ctx.saved_tensors[:11]
+        R, Hd = cx.shape
+        c = BertLayerFn._layer_consts(layer, layer._arena(), None, None) if layer.__dict__.get("_lav_stage_consts") else None
+        F = c["ffn"]
+        dev = x.device
+        e = torch.empty
+        d_pre2, d_dense2, d_x1, d_pre1, d_dense1, d_cx, dx = (e((R, Hd), dtype=bf16, device=dev) for _ in range(7))
+        dh, dqkv = e((R, F), dtype=bf16, device=dev), e((R, 3 * Hd), dtype=bf16, device=dev)
+        splits = (K.splits_for(3 * Hd, Hd, R), K.splits_for(Hd, Hd, R), K.splits_for(F, Hd, R), K.splits_for(Hd, F, R))
+        b = c["bwd"]
+        fields = ctx.c_fields + (dy.data_ptr(),) + b[:20] + splits + (
+            d_pre2.data_ptr(), d_dense2.data_ptr(), dh.data_ptr(), d_x1.data_ptr(), d_pre1.data_ptr(), d_dense1.data_ptr(), d_cx.data_ptr(),
+            dqkv.data_ptr(), dx.data_ptr())
+        side = dw_stream(dev) if _DW_SIDE else None
+        K.bert_layer_bwd(fields, side.cuda_stream if side is not None else None)
+        if side is not None:                                   # operands of the weight-gradient GEMMs: not to be recycled before the side stream ran
+            for t in (d_dense2, h, dh, x1, d_dense1, cx, dqkv, x):
+                t.record_stream(side)
+        return None, dx, None, None, None, None, None, None, None, None, None, None
+
+    @staticmethod
     def backward(ctx, dy, *_unused):
         if dy is None:                                     # nothing downstream used the layer output (grads are not materialised, see forward)
             return (None,) * 12
+        if getattr(ctx, "c_stage", False):
+            return BertLayerFn._backward_c(ctx, dy.contiguous())
         layer, att, (s1, s2), p = ctx.layer, ctx.att, ctx.seeds, ctx.p
         x, qkv, cx, lse, pre1, mean1, rstd1, x1, h_pre, h, pre2, mean2, rstd2 = ctx.saved_tensors
         R, Hd = cx.shape

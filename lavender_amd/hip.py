@@ -103,6 +103,68 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
     return out[:, :N] if out.shape[-1] != N else out
 
 
+# ---- stage-level entries (lavender_amd/csrc/stages.cpp): one C call per fusion-encoder layer pass ------------------------------------
+_BL_FWD_PACK = _struct.Struct("@5i3f3Ii32P")
+_BL_BWD_PACK = _struct.Struct("@5i3f3Ii32P5P4q12P4i9P")
+assert _BL_FWD_PACK.size == C.sizeof(L.BertLayerDesc) and _BL_BWD_PACK.size == C.sizeof(L.BertLayerBwdDesc)
+
+
+def _stage_buffers():
+    b = getattr(_tls, "stage", None)
+    if b is None:
+        rf, rb = C.create_string_buffer(C.sizeof(L.BertLayerDesc)), C.create_string_buffer(C.sizeof(L.BertLayerBwdDesc))
+        b = _tls.stage = (rf, C.cast(rf, C.POINTER(L.BertLayerDesc)), rb, C.cast(rb, C.POINTER(L.BertLayerBwdDesc)))
+    return b
+
+
+_SB_FWD_PACK = _struct.Struct("@5if29P")
+_SB_BWD_PACK = _struct.Struct("@5if29PP2f4P4q13P4i7P")
+assert _SB_FWD_PACK.size == C.sizeof(L.SwinBlockDesc) and _SB_BWD_PACK.size == C.sizeof(L.SwinBlockBwdDesc)
+
+
+def _swin_buffers():
+    b = getattr(_tls, "swin", None)
+    if b is None:
+        rf, rb = C.create_string_buffer(C.sizeof(L.SwinBlockDesc)), C.create_string_buffer(C.sizeof(L.SwinBlockBwdDesc))
+        b = _tls.swin = (rf, C.cast(rf, C.POINTER(L.SwinBlockDesc)), rb, C.cast(rb, C.POINTER(L.SwinBlockBwdDesc)))
+    return b
+
+
+def swin_block_fwd(fields):
+    """fields: lav_swin_block_desc in declaration order (field 7 = address of the window lav_attn_desc)."""
+    rf, pf, _, _ = _swin_buffers()
+    _SB_FWD_PACK.pack_into(rf, 0, *fields)
+    rc = L.lib.lav_swin_block_fwd(_s(), pf)
+    if rc != 0:
+        L.check(rc, "lav_swin_block_fwd")
+
+
+def swin_block_bwd(fields, side_stream):
+    _, _, rb, pb = _swin_buffers()
+    _SB_BWD_PACK.pack_into(rb, 0, *fields)
+    rc = L.lib.lav_swin_block_bwd(_s(), side_stream, pb)
+    if rc != 0:
+        L.check(rc, "lav_swin_block_bwd")
+
+
+def bert_layer_fwd(fields):
+    """fields: the 44 values of lav_bert_layer_desc in declaration order (ints / floats / device addresses, 0 = NULL)."""
+    rf, pf, _, _ = _stage_buffers()
+    _BL_FWD_PACK.pack_into(rf, 0, *fields)
+    rc = L.lib.lav_bert_layer_fwd(_s(), pf)
+    if rc != 0:
+        L.check(rc, "lav_bert_layer_fwd")
+
+
+def bert_layer_bwd(fields, side_stream):
+    """fields: lav_bert_layer_bwd_desc in declaration order (the forward's 44 values first); side_stream: raw hipStream_t or None."""
+    _, _, rb, pb = _stage_buffers()
+    _BL_BWD_PACK.pack_into(rb, 0, *fields)
+    rc = L.lib.lav_bert_layer_bwd(_s(), side_stream, pb)
+    if rc != 0:
+        L.check(rc, "lav_bert_layer_bwd")
+
+
 import os as _os
 _TN_BLOCKS = int(_os.environ.get("LAV_TN_BLOCKS", "192"))      # probe hook: target blocks per weight-gradient GEMM
 

@@ -500,3 +500,57 @@ def test_captioning_seq2seq_matches_oracle_and_golden(golden_dir):
     d32 = (lg.cpu() - b).abs().max().item()
     print("fp32 validation mode, seq2seq: max|d|", d32)
     assert d32 <= 1e-3
+
+
+@pytest.mark.parametrize("size", ["micro", "base_2l"])
+def test_stage_level_c_entries_match_the_per_kernel_path(size):
+    """lav_bert_layer_fwd / _bwd and lav_swin_block_fwd / _bwd (csrc/stages.cpp; engine.STAGE_C) enqueue the same kernels with the same arguments
+    as the per-kernel paths of engine.BertLayerFn / engine.SwinBlockFn (drop-path row scales, skipped k-tiles of dropped samples, head-major
+    qkv and the side-stream bias-table gradient included): a train-mode step (dropout 0.1 in both modes, identical seeds) must give BIT-identical logits
+    and weight gradients (the side stream's read-modify-writes; vectors accumulated with atomics to 1e-5), both for a layer whose
+    residual is the bf16 input (first layer of the micro model: materialised pair gather) and for layers fed by the recomputed
+    LayerNorm residual, at micro width and at the headline width (hidden 768: first layer through the pair map = per-kernel path)."""
+    from tests.helpers import Tok, make_args
+    import lavender_amd as LA
+    import lavender_amd.engine as E
+    from lavender_amd import hip as K
+    from lavender_amd.dist import set_seed
+    B = 4
+    set_seed(88)
+    bert = "micro" if size == "micro" else "b2l"                 # b2l: hidden 768, 12 heads, 2 layers on the micro Swin
+    args = make_args("micro", bert, B)
+    vocab = BERT_CFGS[bert]["vocab"]
+    m = LA.LAVENDER_Pretrain_MLM(args, Tok()).cuda()
+    ar = m.arena()
+    ag = LA.Agent_Pretrain_MLM(args, m)
+    b = make_batch(B, vocab=vocab)
+    torch.manual_seed(5)
+    b.update(ag.masking(b["txt"], b["mask"]))
+    batch = ag.prepare_batch(b)
+    wnames = [n for n, p in m.named_parameters() if p.dim() == 2 and n.endswith("weight") and "embeddings" not in n]
+
+    def run(stage_c):
+        E.STAGE_C = stage_c
+        K.reseed(4321)
+        np.random.seed(3)
+        m.train()
+        ar.zero_grad()
+        out = m(batch)
+        logits = (out["out_mtm"].clone(), out["out_vtm"].clone())
+        ls = (ag.loss_func(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten(), batch["_n_mtm"]) +
+              ag.loss_func(out["out_vtm"].flatten(0, 1), out["ans_vtm"].flatten(), B * 4))
+        ls.backward()
+        torch.cuda.synchronize()
+        return logits, {n: ar.params[n].grad.clone() for n in wnames}, ar.grad.clone()
+
+    keep = E.STAGE_C
+    try:
+        ref_logits, ref, ref_all = run(False)
+        for rep in range(3):
+            logits, got, got_all = run(True)
+            assert torch.equal(logits[0], ref_logits[0]) and torch.equal(logits[1], ref_logits[1]), rep
+            bad = [n for n in wnames if not torch.equal(got[n], ref[n])]
+            assert not bad, (rep, bad[:5])
+            assert ((got_all - ref_all).norm() / ref_all.norm()).item() < 1e-5
+    finally:
+        E.STAGE_C = keep

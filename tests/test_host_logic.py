@@ -347,3 +347,34 @@ def test_gemm_epilogue_pack_format_matches_the_c_struct():
         got = getattr(st, name)
         assert (got or 0) == v, (name, got, v)
     assert K._EPI_PACK.size <= C.sizeof(L.GemmEpilogue) < K._EPI_PACK.size + 8          # only tail padding may differ
+
+
+def test_stage_descriptor_pack_formats_match_the_c_structs():
+    """lav_bert_layer_desc / lav_bert_layer_bwd_desc / lav_swin_block_desc / lav_swin_block_bwd_desc are filled with one struct.pack_into each
+    (lavender_amd/hip.py:_BL_FWD_PACK / _BL_BWD_PACK / _SB_FWD_PACK / _SB_BWD_PACK):
+    every value must land in the field the ctypes declaration (= include/lavender_hip.h) gives it."""
+    import ctypes as C
+    from lavender_amd import _lib as L, hip as K
+
+    def flat_fields(st, prefix=()):
+        out = []
+        for name, ct in st._fields_:
+            if isinstance(ct, type) and issubclass(ct, C.Structure):
+                out += flat_fields(ct, prefix + (name,))
+            else:
+                out.append((prefix + (name,), ct))
+        return out
+
+    for st, packer in ((L.BertLayerDesc, K._BL_FWD_PACK), (L.BertLayerBwdDesc, K._BL_BWD_PACK), (L.SwinBlockDesc, K._SB_FWD_PACK),
+                       (L.SwinBlockBwdDesc, K._SB_BWD_PACK)):
+        fields = flat_fields(st)
+        vals = [(0.25 + i) if ct is L.f32 else (0x2000_0000_0000 + 8 * i) if ct is L.vp else (0xE000_0000 + i) if ct is L.u32 else (700 + i)
+                for i, (_, ct) in enumerate(fields)]
+        raw = C.create_string_buffer(C.sizeof(st))
+        packer.pack_into(raw, 0, *vals)
+        obj = C.cast(raw, C.POINTER(st)).contents
+        for (path, _), v in zip(fields, vals):
+            got = obj
+            for part in path:
+                got = getattr(got, part)
+            assert (got or 0) == v, (path, got, v)
