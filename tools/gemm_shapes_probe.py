@@ -9,6 +9,8 @@ from lavender_amd import hip as K
 from lavender_amd.args import EasyDict
 from lavender_amd.dist import set_seed
 import bench as BN
+import lavender_amd.engine as _E
+_E.STAGE_C = False          # the K.gemm hook below has to see every launch: per-kernel host path (same kernels as the stage-level C entries)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 cfg = dict(num_hidden_layers=12)
