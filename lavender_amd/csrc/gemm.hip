@@ -1622,13 +1622,27 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         // workspace + one reduction pass.  fp32 atomics only remain for ragged N.
         const bool plain = g.e.out_mode == 2 && !g.e.bias && !g.e.act && !g.e.preact && !g.e.gelu_in && g.e.dropout_p <= 0.f &&
                            !g.e.row_scale && !g.e.residual && !g.e.colsum;
+        // A long contraction that is not a multiple of the k-tile (the fusion encoder's token rows n * L: 30280 at cfg4, 33840 at the
+        // reference's shipped batch of 24) used to drop the whole weight gradient onto the 128 x 128 kernel (18 ms per cfg4 step on the
+        // weight-gradient stream).  Split it instead: the first K - K % 64 rows on the large-tile kernels, the < 64-row tail on the small one;
+        // both accumulate into C on this stream (alpha, rowsum_a apply to both parts).
+        // outputs with 160 ... 255 rows (Swin-L stage 0: C = 192) also take the 256-row tiles (a quarter of the tile idle, still well ahead of the
+        // 128 x 128 kernel); LAV_GEMM_TN_MINM=256 restores the old threshold
+        static const int tn_min_m_env = getenv("LAV_GEMM_TN_MINM") ? atoi(getenv("LAV_GEMM_TN_MINM")) : 160;
+        const int tn_min_m = N >= 512 ? tn_min_m_env : (tn_min_m_env > 256 ? tn_min_m_env : 256);      // 192 x 768: 324 -> 198 us; 192 x 192: 112 -> 124 us (stays on the small kernel)
+        if (plain && !g.e.k_keep && M >= tn_min_m && K >= 2048 && (K % PP_BK) != 0 && lav_gemm_tn_kind != 0) {
+            const int K0 = K / BKT * BKT;
+            const int rc0 = lav_gemm_bf16(stream, 2, M, N, K0, A, lda, B, ldb, C, ldc, epi, splits);
+            if (rc0 != LAV_OK) return rc0;
+            return lav_gemm_bf16(stream, 2, M, N, K - K0, (const bf16_t*)A + (long)K0 * lda, lda, (const bf16_t*)B + (long)K0 * ldb, ldb, C, ldc, epi, 1);
+        }
         int kind = 0;                                        // 0: 128x128 two-group kernel, 1: 256x128, 2: 256x256
-        const bool large_ok = plain && (K % BKT) == 0 && (kps % BKT) == 0 && M >= 256 &&
+        const bool large_ok = plain && (K % BKT) == 0 && (kps % BKT) == 0 && M >= tn_min_m &&
                               (!g.e.k_keep || g.e.k_rows_per_group >= BKT);
         if (large_ok && lav_gemm_tn_kind != 0) kind = (N % 256) == 0 && lav_gemm_tn_kind != 1 ? 2 : 1;
         // contraction lengths that are multiples of 32 but not of 64 (Swin stage 3: 7840 token rows): the ping-pong kernel walks k-tiles of 32
         // (k_per_split is a multiple of 64, so only the last split ends on a 32-boundary) -- before round 4 these fell to the 128 x 128 kernel
-        const bool pp_only = !large_ok && plain && (K % PP_BK) == 0 && (K % BKT) != 0 && M >= 256 && (N % 256) == 0 &&
+        const bool pp_only = !large_ok && plain && (K % PP_BK) == 0 && (K % BKT) != 0 && M >= tn_min_m && (N % 256) == 0 &&
                              lav_gemm_pp_tn && lav_gemm_tn_kind != 0 && lav_gemm_tn_kind != 1 &&
                              (!g.e.k_keep || (g.e.k_rows_per_group >= BKT && (K + g.e.k_rows_per_group - 1) / g.e.k_rows_per_group <= 128));
         if (pp_only) kind = 2;

@@ -118,6 +118,23 @@ def test_gemm_tn_contraction_multiple_of_32(splits):
     close(db, 1.25 * (dY.float().cpu() * m).sum(0), atol=0.5, rtol=1e-2, what="fused bias gradient")
 
 
+def test_gemm_tn_ragged_long_contraction_is_split():
+    """A weight gradient whose contraction is long and NOT a multiple of 32 (the fusion encoder's n * L token rows: 40 x 757 = 30280 at cfg4,
+    120 x 282 = 33840 at the reference's shipped batch of 24): lav_gemm_bf16 runs the first K - K % 64 rows on the large-tile kernels and
+    the tail on the 128 x 128 one; both accumulate, the fused bias gradient included."""
+    for (M, N, Kd) in ((768, 768, 30280), (2304, 768, 33840), (768, 384, 4100), (192, 768, 36864), (192, 192, 36872)):      # the last two: Swin-L stage 0 (C = 192 < 256 output rows)
+        dY, X = rb(Kd, M, scale=0.5), rb(Kd, N, seed=1, scale=0.5)
+        dW = torch.full((M, N), 0.25, device="cuda")
+        db = torch.zeros(M, device="cuda")
+        sp = K().splits_for(M, N, Kd)
+        assert sp > 1
+        K().gemm(2, dY, X, M, N, Kd, out=dW, accumulate=True, splits=sp, rowsum_a=db)
+        ref = dY.double().cpu().t() @ X.double().cpu() + 0.25
+        err = (dW.double().cpu() - ref).abs().max().item()
+        assert err < 2e-3 * math.sqrt(Kd), (M, N, Kd, err)
+        close(db, dY.float().cpu().sum(0), atol=0.5, rtol=1e-2, what="fused bias gradient, ragged K")
+
+
 def test_gemm_epilogue_bias_gelu_preact_residual_rowscale():
     M, N, Kd = 300, 264, 128
     A, W, res = rb(M, Kd), rb(N, Kd, seed=1, scale=0.1), rb(M, N, seed=2)
