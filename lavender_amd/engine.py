@@ -180,11 +180,11 @@ class SwinBlockFn(torch.autograd.Function):
         rpg = M // B
         a, mlp = blk.attn, blk.mlp
         keep = _keep(ctx)
-        y1, mean1, rstd1 = K.layernorm_fwd(x, M, C, blk.norm1.weight.data, blk.norm1.bias.data, 1e-5, want_stats=keep)
         win, sh, cfg = geo["window"], geo["shift"], geo["cfg_window"]
         pad = pad_maps(x.device, B, (D, H, Wd), win)
         if STAGE_C and pad is None and _GQ == 1 and x.is_contiguous():
             return SwinBlockFn._forward_c(ctx, x, blk, geo, dp_attn, dp_mlp, keep)
+        y1, mean1, rstd1 = K.layernorm_fwd(x, M, C, blk.norm1.weight.data, blk.norm1.bias.data, 1e-5, want_stats=keep)
         if pad is not None:
             # zero rows AFTER norm1 up to window multiples (video_swin.py:211-215): the qkv GEMM then gives the padded tokens
             # q = k = v = bias, exactly what Linear(0) is in the reference; they attend and are attended to (no mask)
