@@ -228,6 +228,40 @@ def test_base_12l_forward_and_loss_vs_oracle():
     assert abs(ls_mtm.item() - l1.item()) < 1e-2 and abs(ls_vtm.item() - l2.item()) < 1e-2
 
 
+def test_base_12l_forward_at_the_benchmark_batch_vs_oracle():
+    """The shape bench.py times (BASELINE config 2 at batch 32: 2048-window walks in Swin stage 1, 160 fusion sequences, M = 45120
+    GEMMs with their large-tile / 192-row / split-K choices) against the CPU oracle, forward + both losses, eval arithmetic.
+    Same tier-T3 bounds as the batch-2 case; about half a minute of oracle time on the host."""
+    from tests.helpers import build_filled_model
+    from lavender_amd.agent import CrossEntropyIgnore
+    R, P, batch, bc = _oracle_case("base", "b12l", 32)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        np.random.seed(88)
+        ref = R.pretrain_forward(P, batch, "base", bc["heads"])
+        l1, l2 = R.pretrain_loss(ref)
+    m = build_filled_model("base", "b12l", 32).eval()
+    with torch.no_grad():
+        np.random.seed(88)
+        out = m(_to_cuda(batch))
+        lf = CrossEntropyIgnore()
+        ls_mtm = lf(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten())
+        ls_vtm = lf(out["out_vtm"].flatten(0, 1), out["ans_vtm"].flatten())
+    assert (out["ans_vtm"].cpu() == ref["ans_vtm"]).all()
+    for key in ("out_mtm", "out_vtm"):
+        a, b = out[key].float().cpu(), ref[key]
+        assert a.shape == b.shape
+        d = (a - b).abs()
+        agree = (a.argmax(-1) == b.argmax(-1)).float().mean().item()
+        margin = (b.max(-1).values - b.gather(-1, a.argmax(-1, keepdim=True)).squeeze(-1)).max().item()
+        print(key, tuple(a.shape), "max", d.max().item(), "mean", d.mean().item(), "argmax agree", agree, "margin at disagreements", margin,
+              "logit rms", b.pow(2).mean().sqrt().item())
+        assert d.max() < 3e-2 and d.mean() < 5e-3 and agree >= 0.95 and margin < 2 * d.max().item() and margin < 3e-2
+        del a, b, d
+    print("loss", ls_mtm.item(), ls_vtm.item(), "oracle", l1.item(), l2.item())
+    assert abs(ls_mtm.item() - l1.item()) < 1e-2 and abs(ls_vtm.item() - l2.item()) < 1e-2
+
+
 def test_upstream_gradient_scale_is_honoured_without_host_sync():
     """loss / k (gradient accumulation), loss weights or a GradScaler put a factor other than 1 in front of the loss: the stored
     d(loss)/d(logits) is multiplied by the DEVICE scalar (lav_scale_by_scalar), so every gradient scales with it."""
