@@ -166,15 +166,16 @@ def bert_layer_bwd(fields, side_stream):
 
 
 import os as _os
-_TN_BLOCKS = int(_os.environ.get("LAV_TN_BLOCKS", "192"))      # probe hook: target blocks per weight-gradient GEMM
+_TN_BLOCKS = int(_os.environ.get("LAV_TN_BLOCKS", "128"))      # target blocks per weight-gradient GEMM (probe hook; 128 vs 192 etc.: profiles/r04_gemm_experiments.md section 8)
 _TN_MINM = int(_os.environ.get("LAV_GEMM_TN_MINM", "160"))     # fewest output rows that still take the 256-row weight-gradient tiles (gemm.hip: tn_min_m)
 
 
 def splits_for(M, N, K, keep=False):
     """split-K factor for weight-gradient GEMMs, matched to the kernel lav_gemm_bf16 picks for the shape (256x256 tiles
     when M >= 256, N % 256 == 0 and K % 64 == 0; 256x128 when only N % 256 fails; else 128x128).  Measured on MI355X
-    (tools/tn_probe.py): every variant holds one block per CU and is fastest when tiles x splits lands just under 256;
-    partial tiles go to a workspace and are summed by one reduction pass, so extra splits are cheap."""
+    (tools/tn_probe.py): every variant holds one block per CU and is fastest IN ISOLATION when tiles x splits lands just under
+    256; in the step these launches share the chip with the input-gradient chain of the compute stream, which is the critical
+    path, and about half the CUs is the better target (fewer partial tiles through the workspace, CUs left to the other stream)."""
     if M >= (_TN_MINM if N >= 512 else max(_TN_MINM, 256)) and (K % 64 == 0 or (K % 32 == 0 and N % 256 == 0) or (K >= 2048 and not keep)):   # ragged long K: lav_gemm_bf16 splits off the < 64-row tail
         tiles = ((M + 255) // 256) * (N // 256 if N % 256 == 0 else (N + 127) // 128)
         return int(max(1, min(_TN_BLOCKS // tiles if tiles <= _TN_BLOCKS else 1, K // 256)))
