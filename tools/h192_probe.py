@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lavender_amd import hip as K
 from lavender_amd import _lib as L
-from tools.win_var_probe import bench
+from tools._bench import bench
 bf = torch.bfloat16
 for (M, N, Kd, kw) in ((45120, 768, 3072, "r"), (45120, 768, 3072, "bdr"), (45120, 768, 2304, "r"), (45120, 768, 768, ""), (45120, 768, 768, "bdr"),
                        (45120, 2304, 768, "b"), (36096, 768, 3072, "r"), (31360, 512, 2048, "")):

@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lavender_amd import hip as K
-from tools.win_var_probe import bench
+from tools._bench import bench
 
 B = 8
 tot = [0.0, 0.0, 0.0]
