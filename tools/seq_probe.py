@@ -1,5 +1,4 @@
-"""GPU probe: fusion (sequence) attention forward / backward on the step's shapes; with dropout, the counter hash in every kernel vs the
-precomputed keep bits (lav_attn_desc.drop_bits: generator timed separately and inside the forward)."""
+"""GPU probe: fusion (sequence) attention forward / backward on the step's shapes, with and without dropout."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,22 +10,12 @@ for n, L, p in SHAPES:
     heads, Hd = 12, 768
     qkv = torch.randn(n * L, 3 * Hd, device="cuda").bfloat16()
     km = torch.ones(n, L, dtype=torch.int32, device="cuda")
-    lse = out = dqkv = None
+    att = K.Attn(1, heads, 64, n_seq=n, L=L, key_mask=km, dropout_p=p, seed=123)
+    lse = torch.empty(att.lse_elems(), device="cuda")
+    out = torch.empty(n * L, Hd, device="cuda", dtype=torch.bfloat16)
     dout = torch.randn(n * L, Hd, device="cuda").bfloat16()
-    for mode in ("hash", "bits", "bits prefilled"):
-        att = K.Attn(1, heads, 64, n_seq=n, L=L, key_mask=km, dropout_p=p, seed=123)
-        tg = 0.0
-        if mode != "hash":
-            nb = att.dropbits_elems()
-            if not nb:
-                continue
-            buf = torch.empty(nb, dtype=torch.int32, device="cuda")
-            att.set_dropbits(buf, filled=(mode == "bits prefilled"))
-            tg = bench(att.dropbits)
-        lse = torch.empty(att.lse_elems(), device="cuda")
-        out = torch.empty(n * L, Hd, device="cuda", dtype=torch.bfloat16)
-        dqkv = torch.empty_like(qkv)
-        tf = bench(lambda: att.fwd(qkv, out, lse))
-        tb = bench(lambda: att.bwd(qkv, out, dout, lse, dqkv, None))
-        fl = n * heads * 4 * L * L * 64
-        print(f"seq n={n} L={L} p={p} {mode:15s}: fwd {tf:7.1f} us ({fl/tf/1e6:5.0f} TF/s)  bwd {tb:7.1f} us ({2.5*fl/tb/1e6:5.0f} TF/s)  generator {tg:6.1f} us", flush=True)
+    dqkv = torch.empty_like(qkv)
+    tf = bench(lambda: att.fwd(qkv, out, lse))
+    tb = bench(lambda: att.bwd(qkv, out, dout, lse, dqkv, None))
+    fl = n * heads * 4 * L * L * 64
+    print(f"seq n={n} L={L} p={p}: fwd {tf:7.1f} us ({fl/tf/1e6:5.0f} TF/s)  bwd {tb:7.1f} us ({2.5*fl/tb/1e6:5.0f} TF/s)", flush=True)
