@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 const char* lav_last_error(void);
-int lav_abi_version(void);   /* 4: lav_gemm_epilogue.c_pad_writable; 3: a_rowmap / res_rowmap / res_ln_*; 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
+int lav_abi_version(void);   /* 5: lav_layernorm_set_defer / lav_layernorm_flush; 4: lav_gemm_epilogue.c_pad_writable; 3: a_rowmap / res_rowmap / res_ln_*; 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM with fused epilogue.  Replaces every nn.Linear on the path (video_swin.py:73-79,137-139,
@@ -147,6 +147,15 @@ int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, long lddy, 
                       const lav_ln_gather* gather, const float* gamma, const float* mean, const float* rstd,
                       const void* add_in, long ldadd, void* dx, long lddx, float* dgamma, float* dbeta,
                       const lav_ln_bwd_extra* extra);
+
+/* Deferred column reductions.  lav_layernorm_set_defer(1): every following lav_layernorm_bwd (also the ones the stage-level entries issue)
+ * only runs its row pass -- dx (and dx2) are complete as before -- and QUEUES the reduction of its per-block partials into dgamma / dbeta /
+ * colsum; lav_layernorm_flush(stream) completes all queued reductions of that stream in ONE launch.  The three vectors are parameter
+ * gradients (nn.LayerNorm weight / bias, the bias of the dense layer in front): nothing in the dy -> dx chain reads them, so the caller
+ * flushes where gradients become final (before the gradient exchange, the norm, the optimizer).  A call flushes by itself when 48
+ * reductions are queued or its scratch arena is full.  Returns the previous mode / an error code.  Default: off. */
+int lav_layernorm_set_defer(int on);
+int lav_layernorm_flush(void* stream);
 
 /* Row-wise helper: out = row_scale[row/rpg] * gelu'(gelu_in) * dropout(seed; in), column sums into colsum.
  * Produces a dense-branch gradient from a residual-stream gradient (inverse of the GEMM epilogue's dropout /

@@ -97,6 +97,8 @@ _SIGS = {
     "lav_bert_layer_bwd": (i32, [vp, vp, P(BertLayerBwdDesc)]),
     "lav_swin_block_fwd": (i32, [vp, P(SwinBlockDesc)]),
     "lav_swin_block_bwd": (i32, [vp, vp, P(SwinBlockBwdDesc)]),
+    "lav_layernorm_set_defer": (i32, [i32]),
+    "lav_layernorm_flush": (i32, [vp]),
     "lav_layernorm_fwd": (i32, [vp, i32, i32, vp, i64, P(LnGather), vp, vp, f32, vp, i64, vp, vp, P(LnF32)]),
     "lav_layernorm_bwd": (i32, [vp, i32, i32, vp, i64, vp, i64, P(LnGather), vp, vp, vp, vp, i64, vp, i64, vp, vp,
                                 P(LnBwdExtra)]),

@@ -175,6 +175,9 @@ class ParamArena:
         return lo, hi
 
     def notify(self, event):
+        if self.listeners and self.grad.is_cuda:
+            from . import hip as K
+            K.layernorm_flush()                               # a range of gradients is final: complete its queued LayerNorm column reductions first
         for f in self.listeners:
             f(event)
 

@@ -264,6 +264,69 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restr
     }
 }
 
+// ---- deferred column reductions (lav_layernorm_set_defer / lav_layernorm_flush) -------------------------------------------------
+// 78 LayerNorm backwards per pretrain step each put an 8-us finish launch (plus its dispatch gap) into the dy -> dx chain of the compute
+// stream although nothing reads dgamma / dbeta / the bias column sums before the gradients are exchanged or stepped.  In deferred mode
+// the row pass writes its per-block partials into a per-stream bump arena and the reduction is queued as a JOB; lav_layernorm_flush
+// runs ALL queued jobs of the stream in one launch (job table in the kernel arguments).  Same stream, so the arena is reused from the
+// start after a flush; when the table or the arena is full the call flushes by itself.
+#define LN_MAX_JOBS 48
+struct LnFinishJob { const float* part; float* o0; float* o1; float* o2; int nblk, C, blk0, pad_; };
+struct LnFinishJobs { int n, total_blocks; LnFinishJob j[LN_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void ln_bwd_finish_many_kernel(LnFinishJobs J) {
+    __shared__ float red[8][33];
+    int ji = 0;
+    while (ji + 1 < J.n && (int)blockIdx.x >= J.j[ji + 1].blk0) ++ji;     // block-uniform scan of <= 48 entries held in SGPRs / kernarg
+    const LnFinishJob& job = J.j[ji];
+    const int w = blockIdx.y;
+    float* out = w == 0 ? job.o0 : (w == 1 ? job.o1 : job.o2);
+    if (!out) return;
+    const int nblk = job.nblk, C = job.C;
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, c = ((int)blockIdx.x - job.blk0) * 32 + cl;
+    float s = 0.f;
+    if (c < C) {
+        const float* p = job.part + (long)w * nblk * C + c;
+#pragma unroll 8
+        for (int b = sl; b < nblk; b += 8) s += p[(long)b * C];
+    }
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][cl];
+        atomicAdd(out + c, t);
+    }
+}
+
+struct LnDefer { void* stream; float* arena; size_t bytes, used; LnFinishJobs jobs; };
+static LnDefer g_lndefer[4] = {};
+static int g_ln_defer_on = 0;
+#define LN_DEFER_ARENA ((size_t)384 << 20)
+
+static LnDefer* ln_defer_state(void* stream, bool create) {
+    for (auto& d : g_lndefer) if (d.arena && d.stream == stream) return &d;
+    if (!create) return nullptr;
+    for (auto& d : g_lndefer) if (!d.arena) {
+        if (hipMalloc((void**)&d.arena, LN_DEFER_ARENA) != hipSuccess) { (void)hipGetLastError(); d.arena = nullptr; return nullptr; }
+        d.stream = stream; d.bytes = LN_DEFER_ARENA; d.used = 0; d.jobs.n = 0; d.jobs.total_blocks = 0;
+        return &d;
+    }
+    return nullptr;                                          // more than 4 streams use the deferred mode: those calls finish at once
+}
+
+static int ln_defer_flush(LnDefer* d) {
+    if (!d || d->jobs.n == 0) return LAV_OK;
+    hipLaunchKernelGGL(ln_bwd_finish_many_kernel, dim3(d->jobs.total_blocks, 3), dim3(256), 0, (hipStream_t)d->stream, d->jobs);
+    d->jobs.n = 0; d->jobs.total_blocks = 0; d->used = 0;
+    return lav_check_launch("lav_layernorm_flush");
+}
+
+extern "C" int lav_layernorm_set_defer(int on) { const int old = g_ln_defer_on; g_ln_defer_on = on != 0; return old; }
+
+extern "C" int lav_layernorm_flush(void* stream) { return ln_defer_flush(ln_defer_state(stream, false)); }
+
 // per-stream scratch for the column partials (same pattern as the split-K workspace of gemm.hip: calls on one stream are ordered)
 struct LnWs { void* stream; float* ptr; size_t bytes; };
 static LnWs g_lnws[8] = {};
@@ -379,7 +442,15 @@ extern "C" int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, 
     // read it has run (the row-pass stream waits for that event -- eight LayerNorm backwards later, so it never actually waits).
     hipStream_t fs = (hipStream_t)a.ex.finish_stream;
     LnRing* slot = nullptr;
-    if (use_part && any_col && grid >= 64) {
+    LnDefer* defer = nullptr;
+    const size_t part_bytes = (size_t)3 * grid * C * sizeof(float);
+    if (use_part && any_col && grid >= 64 && g_ln_defer_on && !(fs && fs != s)) {
+        defer = ln_defer_state(stream, true);
+        if (defer && part_bytes > defer->bytes) defer = nullptr;
+        if (defer && (defer->jobs.n == LN_MAX_JOBS || defer->used + part_bytes > defer->bytes)) { if (int rc = ln_defer_flush(defer)) return rc; }
+        if (defer) { a.part = (float*)((char*)defer->arena + defer->used); defer->used += (part_bytes + 255) & ~(size_t)255; }
+    }
+    if (!defer && use_part && any_col && grid >= 64) {
         if (fs && fs != s) {
             slot = ln_ring_slot((size_t)3 * grid * C * sizeof(float));
             if (slot) {
@@ -393,7 +464,11 @@ extern "C" int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, 
     const bool x32 = a.ex.x_f32 != 0;
     LN_DISPATCH(K_, x32)
 #undef K_
-    if (a.part) {
+    if (defer) {
+        LnFinishJob& jb = defer->jobs.j[defer->jobs.n++];
+        jb.part = a.part; jb.o0 = dgamma; jb.o1 = dbeta; jb.o2 = a.ex.colsum; jb.nblk = grid; jb.C = C; jb.blk0 = defer->jobs.total_blocks; jb.pad_ = 0;
+        defer->jobs.total_blocks += (C + 31) / 32;
+    } else if (a.part) {
         hipStream_t rs = s;
         if (slot) {
             (void)hipEventRecord(slot->produced, s);

@@ -13,7 +13,7 @@ extern "C" void lav_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* lav_last_error(void) { return g_err; }
-extern "C" int lav_abi_version(void) { return 4; }
+extern "C" int lav_abi_version(void) { return 5; }
 
 // Split-K workspaces, LDS-size attributes, window tables and the optimizer's partial-sum buffer are process-wide (keyed by
 // stream at most): ONE device per process, the deployment model of this library (one rank per GPU).  Every launch checks it,

@@ -97,11 +97,14 @@ def ln_bwd(dy, *args, **kw):
     stream -- everything that reads those gradients already joins that stream (dw_join, the reducer's range events)."""
     if _DW_SIDE and _LN_SIDE:
         kw["finish_stream"] = dw_stream(dy.device)
-    return K.layernorm_bwd(dy, *args, **kw)
+    return K.layernorm_bwd(dy, *args, flush=False, **kw)     # deferred column reductions: completed by dw_join / arena events (K.layernorm_flush)
 
 
 def dw_join(device=None):
-    """main stream waits for every weight-gradient kernel issued so far (before the gradients are read)."""
+    """main stream waits for every weight-gradient kernel issued so far (before the gradients are read); the LayerNorm column
+    reductions queued on the main stream (lav_layernorm_set_defer) are completed first."""
+    if torch.cuda.is_available():
+        K.layernorm_flush()
     for dev, st in _dw_streams.items():
         if device is None or dev == device:
             torch.cuda.current_stream(dev).wait_stream(st)

@@ -42,6 +42,8 @@ def _ld(t):
 
 import struct as _struct
 import threading as _threading
+import os as _os_mod
+_os_env = _os_mod.environ.get
 
 # lav_gemm_epilogue, packed in ONE struct.pack_into instead of ~30 ctypes field stores (13 -> ~6 us per call on ~450 calls per step:
 # the launch thread's Python time is what the step falls back on when the GPU gets faster).  Native alignment ("@") reproduces the C
@@ -228,10 +230,24 @@ def layernorm_fwd(x, rows, Cn, gamma, beta, eps, gather=None, out=None, want_sta
     return y, mean, rstd
 
 
+LN_DEFER = _os_env("LAV_LN_DEFER", "1") != "0"      # deferred column reductions of the LayerNorm backward (lav_layernorm_set_defer): one finish launch per flush
+if LN_DEFER:
+    L.lib.lav_layernorm_set_defer(1)
+
+
+def layernorm_flush():
+    """complete the queued column reductions (dgamma / dbeta / colsum) of the current stream: lav_layernorm_flush"""
+    if LN_DEFER:
+        rc = L.lib.lav_layernorm_flush(_s())
+        if rc != 0:
+            L.check(rc, "lav_layernorm_flush")
+
+
 def layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dgamma, dbeta, gather=None, add_in=None, dx=None, dx2=None,
-                  row_scale=None, rows_per_group=1, dropout_p=0.0, seed=0, colsum=None, finish_stream=None):
+                  row_scale=None, rows_per_group=1, dropout_p=0.0, seed=0, colsum=None, finish_stream=None, flush=True):
     """finish_stream (a torch.cuda.Stream): dgamma / dbeta / colsum are completed there (lav_ln_bwd_extra.finish_stream); the
-    caller joins it before reading them."""
+    caller joins it before reading them.  flush=False (the engine): in the deferred mode the three vectors are only complete after
+    layernorm_flush() on this stream; the default completes them before returning, as without the mode."""
     dev = dy.device
     if dx is None:
         dx = torch.empty((rows * 4, Cn // 4) if gather is not None else (rows, Cn), dtype=bf16, device=dev)
@@ -254,6 +270,8 @@ def layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dgamma, dbeta, gather=None
     L.check(L.lib.lav_layernorm_bwd(_s(), rows, Cn, _p(dy), _ld(dy), _p(x), ldx, _gather(gather), _p(gamma), _p(mean),
                                     _p(rstd), _p(add_in), (_ld(add_in) if add_in is not None else 0), _p(dx), lddx,
                                     _p(dgamma), _p(dbeta), ex), "lav_layernorm_bwd")
+    if flush:
+        layernorm_flush()
     return dx
 
 

@@ -343,6 +343,40 @@ def test_gemm_ragged_vocab_with_writable_padding():
     assert torch.equal(ref[:, :V], buf[:, :V]) and (ref[:, V:] == 7.0).all()
 
 
+def test_layernorm_bwd_deferred_column_reductions_match_immediate_ones():
+    """lav_layernorm_set_defer / lav_layernorm_flush: the row pass queues the reduction of its per-block column partials and ONE launch per
+    flush completes all of them.  60 backward calls on three shapes (more than the 48-entry job table: the 49th call flushes by itself),
+    two of them accumulating into the SAME vectors, against the same calls completed one by one: dgamma / dbeta / colsum bit-identical
+    (the same partials are summed in the same order), dx identical."""
+    from lavender_amd import hip as KK
+    if not KK.LN_DEFER:
+        pytest.skip("LAV_LN_DEFER=0")
+    shapes = [(31360, 512), (4512, 768), (7840, 1024)]
+    def run(flush_each):
+        outs = []
+        shared = [torch.zeros(C, device="cuda") for C in (512, 512, 512)]
+        for i in range(60):
+            rows, C = shapes[i % 3]
+            x, dy = rb(rows, C, seed=i), rb(rows, C, seed=100 + i)
+            g = (1.0 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(7 + i))).cuda()
+            _, mean, rstd = KK.layernorm_fwd(x, rows, C, g, torch.zeros(C, device="cuda"), 1e-5)
+            if i % 3 == 0 and i < 6:
+                dg, db, cs = shared                                               # two calls add into the same three vectors
+            else:
+                dg, db, cs = (torch.zeros(C, device="cuda") for _ in range(3))
+            dx2 = torch.empty(rows, C, dtype=bf16, device="cuda")
+            dx = KK.layernorm_bwd(dy, x, rows, C, g, mean, rstd, dg, db, dx2=dx2, dropout_p=0.1, seed=i, colsum=cs, flush=flush_each)
+            outs.append((dx, dx2, dg, db, cs))
+        KK.layernorm_flush()
+        torch.cuda.synchronize()
+        return outs
+    a, b = run(True), run(False)
+    for i, (ta, tb) in enumerate(zip(a, b)):
+        for u, v, what in zip(ta, tb, ("dx", "dx2", "dgamma", "dbeta", "colsum")):
+            assert torch.equal(u, v), f"call {i}: {what} differs between immediate and deferred reduction"
+    assert a[0][2].abs().max() > 0
+
+
 def test_gemm_dropout_mask_consistent_with_layernorm_bwd():
     """The GEMM epilogue and the LN backward regenerate the SAME counter-based dropout mask."""
     M, N, Kd, p, seed = 256, 128, 64, 0.3, 1234
