@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 const char* lav_last_error(void);
-int lav_abi_version(void);   /* 5: lav_layernorm_set_defer / lav_layernorm_flush; 4: lav_gemm_epilogue.c_pad_writable; 3: a_rowmap / res_rowmap / res_ln_*; 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
+int lav_abi_version(void);   /* 5: lav_layernorm_set_defer / lav_layernorm_flush, lav_attn_desc.bias_map / lav_attention_build_bias_map; 4: lav_gemm_epilogue.c_pad_writable; 3: a_rowmap / res_rowmap / res_ln_*; 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM with fused epilogue.  Replaces every nn.Linear on the path (video_swin.py:73-79,137-139,
@@ -208,6 +208,9 @@ typedef struct lav_attn_desc {
     int qkv_headmajor;        /* window mode with the precomputed tables (comb != NULL) only: the qkv operand is laid out
                                  [q | k | v][head][token row][head_dim] (as lav_gemm_epilogue.hm_heads writes it) instead of row-major
                                  (rows, 3 * heads * head_dim); a window's operand pieces are then whole 128-byte lines.  dqkv stays row-major */
+    const int32_t* bias_map;  /* window mode with the precomputed tables, optional: int32 (2, n_types, 65536) filled ONCE per geometry by
+                                 lav_attention_build_bias_map -- the bias-table row (and shift-mask / padding class) of every element of comb / combT;
+                                 lav_attention_build_bias then only gathers the current table values through it (same bits, ~4x less time) */
 } lav_attn_desc;
 
 int lav_attention_fwd(void* stream, const lav_attn_desc* d, const void* qkv, void* out, float* lse);
@@ -227,6 +230,9 @@ size_t lav_attention_lse_elems(const lav_attn_desc* d);
 /* Fills d->comb and d->combT (each n_types*heads*8*8*64*16 bf16) from the current bias table: value(q,k) =
  * table[index(q,k), head] + (region(q) != region(k) ? -100 : 0), -30000 for padded keys (video_swin.py:153-160). */
 int lav_attention_build_bias(void* stream, const lav_attn_desc* d);
+/* Fills d->bias_map (see lav_attn_desc.bias_map) for the descriptor's geometry: depends on the window, the configured window and the shift
+ * pattern only (relative_position_index and compute_mask, video_swin.py:118-135,290-305), not on the parameters. */
+int lav_attention_build_bias_map(void* stream, const lav_attn_desc* d);
 
 /* ---------------------------------------------------------------------------------------------
  * Patch embedding im2col (PatchEmbed3D, video_swin.py:388-405): (B,3,T,H,W) fp32 NCDHW clip ->

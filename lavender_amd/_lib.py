@@ -51,7 +51,7 @@ class AttnDesc(C.Structure):
                 ("wd", i32), ("wh", i32), ("ww", i32), ("sd", i32), ("sh", i32), ("sw", i32), ("cfg_wh", i32),
                 ("cfg_ww", i32), ("cfg_wd", i32), ("bias_table", vp), ("n_seq", i32), ("L", i32), ("key_mask", vp),
                 ("dropout_p", f32), ("seed", u32), ("scale", f32), ("tok_table", vp), ("win_type", vp), ("type_region", vp),
-                ("n_types", i32), ("comb", vp), ("combT", vp), ("causal_from", i32), ("qkv_headmajor", i32)]
+                ("n_types", i32), ("comb", vp), ("combT", vp), ("causal_from", i32), ("qkv_headmajor", i32), ("bias_map", vp)]
 
 
 class BertLayerDesc(C.Structure):          # struct lav_bert_layer_desc (stage-level entries)
@@ -109,6 +109,7 @@ _SIGS = {
     "lav_attention_bwd_bias": (i32, [vp, P(AttnDesc), vp, vp, vp, vp]),
     "lav_attention_bias_split": (i32, [P(AttnDesc)]),
     "lav_attention_lse_elems": (C.c_size_t, [P(AttnDesc)]),
+    "lav_attention_build_bias_map": (i32, [vp, P(AttnDesc)]),
     "lav_attention_build_bias": (i32, [vp, P(AttnDesc)]),
     "lav_patch_im2col": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "lav_video_embed_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, vp, i64, vp, vp]),

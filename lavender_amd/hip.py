@@ -327,6 +327,9 @@ def window_tables(device, D, H, W, window, shift):
     return out
 
 
+BIAS_MAP = _os_env("LAV_BIAS_MAP", "1") != "0"     # window bias fragments gathered through a per-geometry index map (lav_attn_desc.bias_map); 0 = index arithmetic in every build
+
+
 class Attn:
     """Descriptor + scratch for one attention call (window or sequence mode)."""
 
@@ -352,6 +355,18 @@ class Attn:
             d.tok_table, d.win_type, d.type_region, d.n_types = _p(t["tok"]), _p(t["wtype"]), _p(t["region"]), t["ntypes"]
             d.comb, d.combT = _p(self.comb), _p(self.combT)
             self._tables = t
+            if BIAS_MAP:
+                # the index half of the table build (relative_position_index + shift mask + padding classes): once per geometry
+                mkey = ("bias_map", kw["cfg_wd"], kw["cfg_wh"], kw["cfg_ww"])
+                bm = t.get(mkey)
+                if bm is None:
+                    bm = torch.empty(2 * t["ntypes"] * 65536, dtype=torch.int32, device=dev)
+                    d.bias_map = _p(bm)
+                    L.check(L.lib.lav_attention_build_bias_map(_s(), C.byref(d)), "lav_attention_build_bias_map")
+                    bm.record_stream(torch.cuda.current_stream(dev))
+                    t[mkey] = bm
+                d.bias_map = _p(bm)
+                self._bias_map = bm
             L.check(L.lib.lav_attention_build_bias(_s(), C.byref(d)), "lav_attention_build_bias")
 
     def lse_elems(self):

@@ -542,6 +542,42 @@ def test_window_attention_fwd_bwd(case):
 
 
 @pytest.mark.parametrize("case", [
+    (2, 5, 14, 14, 2, (5, 7, 7), (0, 3, 3), (8, 7, 7)),       # N=245 shifted: four mask types
+    (1, 5, 28, 28, 4, (5, 7, 7), (0, 0, 0), (8, 7, 7)),       # unshifted, 16 windows
+    (2, 1, 14, 14, 1, (1, 7, 7), (0, 3, 3), (8, 7, 7)),       # N=49
+    (2, 4, 14, 7, 3, (4, 7, 7), (0, 3, 0), (8, 7, 7)),        # N=196, one shifted axis
+    (1, 16, 7, 7, 2, (8, 7, 7), (4, 0, 0), (8, 7, 7)),        # N=392 does not take this path; (8,7,7) clamps nothing here: skipped below
+    (1, 5, 12, 12, 2, (5, 6, 6), (0, 3, 3), (8, 12, 12)),     # spatial window clamped below the configured one: N=180
+])
+def test_window_bias_tables_through_the_geometry_map_are_bit_identical(case):
+    """lav_attn_desc.bias_map: the (bias + shift mask + key padding) fragment tables built by a gather through the per-geometry index map
+    equal the tables built with the index arithmetic in the kernel, bit for bit, and follow the CURRENT bias table (second build after the
+    table changed)."""
+    from lavender_amd import hip as KK
+    B, D, H, W, heads, win, shift, cfg = case
+    if win[0] * win[1] * win[2] > 256:
+        pytest.skip("large windows do not use the precomputed tables")
+    table = (0.5 * torch.randn((2 * cfg[0] - 1) * (2 * cfg[1] - 1) * (2 * cfg[2] - 1), heads)).cuda()
+    def build(use_map):
+        old = KK.BIAS_MAP
+        KK.BIAS_MAP = use_map
+        try:
+            att = KK.Attn(0, heads, 32, B=B, D=D, H=H, W=W, wd=win[0], wh=win[1], ww=win[2], sd=shift[0], sh=shift[1], sw=shift[2],
+                          cfg_wd=cfg[0], cfg_wh=cfg[1], cfg_ww=cfg[2], bias_table=table)
+        finally:
+            KK.BIAS_MAP = old
+        torch.cuda.synchronize()
+        return att
+    a0, a1 = build(False), build(True)
+    assert hasattr(a1, "_bias_map") and not hasattr(a0, "_bias_map")
+    assert torch.equal(a0.comb.view(torch.int16), a1.comb.view(torch.int16)) and torch.equal(a0.combT.view(torch.int16), a1.combT.view(torch.int16))
+    table.mul_(-1.5)                                                          # the optimizer moved the table: the cached map still applies
+    b0, b1 = build(False), build(True)
+    assert torch.equal(b0.comb.view(torch.int16), b1.comb.view(torch.int16)) and torch.equal(b0.combT.view(torch.int16), b1.combT.view(torch.int16))
+    assert not torch.equal(a1.comb.view(torch.int16), b1.comb.view(torch.int16))
+
+
+@pytest.mark.parametrize("case", [
     (2, 5, 14, 14, 64, 2, (5, 7, 7), (0, 3, 3)),        # N=245 shifted
     (3, 5, 14, 14, 128, 4, (5, 7, 7), (0, 0, 0)),       # four heads, unshifted
     (2, 1, 14, 14, 32, 1, (1, 7, 7), (0, 3, 3)),        # N=49
