@@ -65,6 +65,21 @@ __device__ __forceinline__ void drop_pair(uint32_t seed, uint32_t idx, uint32_t 
     m1 = (h >> 16) >= thresh16 ? inv : 0.f;
 }
 
+// dK / dV pass: a lane holds ONE key and four queries per register group, and the dropout hash is per (query, key PAIR) -- lanes j and
+// j ^ 1 (keys 2p and 2p + 1) need the same four hashes and differ only in the 16-bit half they test.  Each lane of the pair therefore
+// computes two of the four (two quarter-rate multiplies each) and fetches the other two from its neighbour with a DPP quad_perm move
+// (one full-rate VALU op): same hashes, same keep decisions, half the multiplies.
+__device__ __forceinline__ uint32_t lane_pair_swap(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void drop_hash4(uint32_t seed, uint32_t base, uint32_t nh, bool odd, uint32_t (&h)[4]) {
+    // element e of the group has index base + e * nh; this lane hashes e = 0, 1 (even key) or e = 2, 3 (odd key)
+    const uint32_t mine = base + (odd ? 2u * nh : 0u);
+    const uint32_t a = lav_hash32(seed, mine), b = lav_hash32(seed, mine + nh);
+    const uint32_t pa = lane_pair_swap(a), pb = lane_pair_swap(b);
+    h[0] = odd ? pa : a; h[1] = odd ? pb : b; h[2] = odd ? a : pa; h[3] = odd ? b : pb;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // forward.  LDS: K image | V image | additive key mask (fp32, 0 / -inf; -inf past the sequence end).
 // ------------------------------------------------------------------------------------------------------
@@ -390,6 +405,8 @@ __global__ __launch_bounds__(256, 2) void seq_dkv3(AttnArgs a, int nprob, const 
                     const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
                     const float dls[4] = {d4.x, d4.y, d4.z, d4.w};
                     float pv[4], dsv[4];
+                    uint32_t h4[4] = {0u, 0u, 0u, 0u};
+                    if (DROP) drop_hash4(a.d.seed, (dcol + (uint32_t)qb) * (uint32_t)a.NH + (uint32_t)(key >> 1), (uint32_t)a.NH, (key & 1) != 0, h4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = r4 * 4 + e;
@@ -399,10 +416,7 @@ __global__ __launch_bounds__(256, 2) void seq_dkv3(AttnArgs a, int nprob, const 
                             if (key >= a.d.causal_from && (qq < a.d.causal_from || key > qq)) pe = 0.f;
                         }
                         float m = 1.f;
-                        if (DROP) {
-                            const uint32_t h = lav_hash32(a.d.seed, (dcol + (uint32_t)(qb + e)) * (uint32_t)a.NH + (uint32_t)(key >> 1));
-                            m = ((h >> sh) & 0xffffu) >= a.thresh16 ? inv_keep : 0.f;
-                        }
+                        if (DROP) m = ((h4[e] >> sh) & 0xffffu) >= a.thresh16 ? inv_keep : 0.f;
                         pv[e] = DROP ? pe * m : pe;
                         dsv[e] = pe * (DROP ? fmaf(dp[r], m, -dls[e]) : dp[r] - dls[e]);
                     }
@@ -806,6 +820,8 @@ __global__ __launch_bounds__(512) void seql_dkv(AttnArgs a, int nprob, int parts
                         const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
                         const float dls[4] = {d4.x, d4.y, d4.z, d4.w};
                         float pv[4], dsv[4];
+                        uint32_t h4[4] = {0u, 0u, 0u, 0u};
+                        if (DROP) drop_hash4(a.d.seed, (dcol + (uint32_t)qb) * (uint32_t)a.NH + (uint32_t)(key >> 1), (uint32_t)a.NH, (key & 1) != 0, h4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int r = r4 * 4 + e;
@@ -815,10 +831,7 @@ __global__ __launch_bounds__(512) void seql_dkv(AttnArgs a, int nprob, int parts
                                 if (key >= a.d.causal_from && (qq < a.d.causal_from || key > qq)) pe = 0.f;
                             }
                             float m = 1.f;
-                            if (DROP) {
-                                const uint32_t h = lav_hash32(a.d.seed, (dcol + (uint32_t)(qb + e)) * (uint32_t)a.NH + (uint32_t)(key >> 1));
-                                m = ((h >> sh) & 0xffffu) >= a.thresh16 ? inv_keep : 0.f;
-                            }
+                            if (DROP) m = ((h4[e] >> sh) & 0xffffu) >= a.thresh16 ? inv_keep : 0.f;
                             pv[e] = DROP ? pe * m : pe;
                             dsv[e] = pe * (DROP ? fmaf(dp[r], m, -dls[e]) : dp[r] - dls[e]);
                         }
