@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 const char* lav_last_error(void);
-int lav_abi_version(void);   /* 5: lav_layernorm_set_defer / lav_layernorm_flush, lav_attn_desc.bias_map / lav_attention_build_bias_map; 4: lav_gemm_epilogue.c_pad_writable; 3: a_rowmap / res_rowmap / res_ln_*; 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
+int lav_abi_version(void);   /* 5: fp16 rows (out_mode 3, residual_f32 / x_f32 = 2, lav_bert_layer_desc.stream_f16), lav_layernorm_set_defer / lav_layernorm_flush, lav_attn_desc.bias_map / lav_attention_build_bias_map; 4: lav_gemm_epilogue.c_pad_writable; 3: a_rowmap / res_rowmap / res_ln_*; 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM with fused epilogue.  Replaces every nn.Linear on the path (video_swin.py:73-79,137-139,
@@ -60,7 +60,7 @@ typedef struct lav_gemm_epilogue {
     long ldr;
     float* colsum;            /* fp32 [N]: atomically accumulates the column sums of the stored values */
     float alpha;              /* 0 is read as 1 */
-    int out_mode;             /* 0 bf16 store, 1 fp32 store, 2 fp32 atomicAdd */
+    int out_mode;             /* 0 bf16 store, 1 fp32 store, 2 fp32 atomicAdd, 3 fp16 store (saturating at +-65504; ldc % 8 == 0, layouts 0 / 1) */
     const float* k_keep;      /* layout 2 only: contraction rows whose k_keep[row / k_rows_per_group]==0 are skipped */
     int k_rows_per_group;
     float* rowsum_a;          /* layout 2 only: fp32 [M] += alpha * sum_k A[k, m] -- the bias gradient sum(dy), fused
@@ -68,8 +68,9 @@ typedef struct lav_gemm_epilogue {
     int preact_is_grad;       /* forward: store act'(z) instead of z (the backward then needs one multiply, no erf); 2 = GELU only,
                                  as ONE BYTE per element: q = round((g + 0.25) * 256 / 1.5), preact is uint8 [M, ldp] */
     int gelu_in_is_grad;      /* backward: gelu_in already holds GELU'(z) (1: bf16, 2: the one-byte code above, ldg in bytes) */
-    int residual_f32;         /* residual is fp32 [M, ldr] (the fp32 residual stream of the post-LN fusion encoder:
-                                 pre = x + dropout(dense(.)) is then stored fp32 with out_mode 1) */
+    int residual_f32;         /* 1: residual is fp32 [M, ldr] (the wide residual stream of the post-LN fusion encoder:
+                                 pre = x + dropout(dense(.)) is then stored fp32 with out_mode 1); 2: residual is fp16 [M, ldr]
+                                 (the same stream as halves -- the shipped form, out_mode 3: 11 mantissa bits against bf16's 8, half the bytes of fp32) */
     const int* a_rowmap;      /* layout 0, N % 256 == 0, K % 64 == 0, splits == 1: logical row m of A is physical row a_rowmap[m]
                                  (int32 [M], device).  The B x B pair expansion of the retrieval / VTM callers
                                  (main_retrieval_mlm.py:62-87, main_pretrain_mlm.py:74-111): the (pairs, L, H) fusion input is never
@@ -117,7 +118,7 @@ typedef struct lav_ln_gather {
  * the pre-LN sums are fp32 GEMM outputs (x_f32 = 1) and the normalised rows are written twice, bf16 for the next GEMM's
  * operand and fp32 (y32) for the next residual add.  y (bf16) may be NULL when only the fp32 copy is wanted. */
 typedef struct lav_ln_f32 {
-    int x_f32;                /* x is fp32 [rows, ldx] */
+    int x_f32;                /* 1: x is fp32 [rows, ldx]; 2: x is fp16 [rows, ldx] (the residual stream stored as halves) */
     void* y32; long ldy32;    /* fp32 copy of the output, or NULL */
 } lav_ln_f32;
 
@@ -137,7 +138,7 @@ typedef struct lav_ln_bwd_extra {
     const float* row_scale; int rows_per_group;
     float dropout_p; uint32_t seed;
     float* colsum;
-    int x_f32;                /* the saved LayerNorm input x is fp32 (see lav_ln_f32) */
+    int x_f32;                /* the saved LayerNorm input x is fp32 (1) or fp16 (2) (see lav_ln_f32) */
     void* finish_stream;      /* NULL or a hipStream_t: the column reduction that produces dgamma / dbeta / colsum (parameter gradients,
                                  not needed by the dy -> dx chain) is enqueued THERE, ordered after the row pass by an event; `stream`
                                  only runs the row pass.  The caller joins finish_stream before it reads those three vectors */
@@ -384,10 +385,11 @@ typedef struct lav_bert_layer_desc {
     const void* w_ff2; const float* b_ff2; const float* ln2_gamma; const float* ln2_beta;
     /* input */
     const void* x;                                         /* bf16 (rows, hidden), rows = n_seq * L */
-    const float* res_pre; const float* res_mean; const float* res_rstd; const float* res_gamma; const float* res_beta;   /* or all NULL */
+    const void* res_pre; const float* res_mean; const float* res_rstd; const float* res_gamma; const float* res_beta;   /* or all NULL */
     /* outputs / activations kept for the backward (lse, h_pre: NULL in a forward that will not be differentiated) */
-    void* qkv; void* cx; float* lse; float* pre1; float* mean1; float* rstd1; void* x1; void* h_pre; void* h;
-    float* pre2; float* mean2; float* rstd2; void* y;
+    void* qkv; void* cx; float* lse; void* pre1; float* mean1; float* rstd1; void* x1; void* h_pre; void* h;
+    void* pre2; float* mean2; float* rstd2; void* y;
+    int stream_f16;                                        /* 0: res_pre / pre1 / pre2 (the pre-LayerNorm residual stream) are fp32 rows; 1: fp16 rows */
 } lav_bert_layer_desc;
 int lav_bert_layer_fwd(void* stream, const lav_bert_layer_desc* d);
 

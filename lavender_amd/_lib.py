@@ -59,7 +59,7 @@ class BertLayerDesc(C.Structure):          # struct lav_bert_layer_desc (stage-l
                 [(n, u32) for n in ("seed_attn", "seed1", "seed2")] + [("causal_from", i32)] +
                 [(n, vp) for n in ("key_mask", "w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_gamma", "ln1_beta", "w_ff1", "b_ff1", "w_ff2", "b_ff2",
                                    "ln2_gamma", "ln2_beta", "x", "res_pre", "res_mean", "res_rstd", "res_gamma", "res_beta", "qkv", "cx", "lse",
-                                   "pre1", "mean1", "rstd1", "x1", "h_pre", "h", "pre2", "mean2", "rstd2", "y")])
+                                   "pre1", "mean1", "rstd1", "x1", "h_pre", "h", "pre2", "mean2", "rstd2", "y")] + [("stream_f16", i32)])
 
 
 class BertLayerBwdDesc(C.Structure):       # struct lav_bert_layer_bwd_desc

@@ -56,6 +56,22 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
 }
 
+// fp16 rows (the fusion encoder's residual stream, late round 4): 8 halves <-> 8 floats.  Stores saturate at the largest finite
+// half instead of overflowing to infinity (pre-LayerNorm sums of a BERT are O(10); the clamp is for checkpoints with outliers).
+typedef _Float16 lav_h8 __attribute__((ext_vector_type(8)));
+typedef float lav_f8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void unpack8_h(const uint4& v, float* f) {
+    const lav_f8 x = __builtin_convertvector(__builtin_bit_cast(lav_h8, v), lav_f8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = x[k];
+}
+__device__ __forceinline__ uint4 pack8_h(const float* f) {
+    lav_f8 x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = __builtin_amdgcn_fmed3f(f[k], -65504.f, 65504.f);
+    return __builtin_bit_cast(uint4, __builtin_convertvector(x, lav_h8));
+}
+
 // erf-GELU (torch.nn.GELU() default / HF "gelu") and its derivative.  erf via Abramowitz-Stegun 7.1.26
 // (|abs err| <= 1.5e-7, far below bf16 resolution) in ~14 VALU ops -- the library erff is ~3x that and made the
 // GELU epilogue cost more than the k-loop of the K=768 GEMMs it is fused into.

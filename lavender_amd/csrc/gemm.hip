@@ -267,7 +267,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
                 }
                 if (has_res) {
                     const long rrow = e.res_rowmap ? e.res_rowmap[grow] : grow;
-                    if (e.residual_f32) {
+                    if (e.residual_f32 == 2) {
+                        pre_r[u] = *(const uint4*)((const _Float16*)e.residual + rrow * e.ldr + gcol);      // fp16 rows: one 16-byte chunk
+                    } else if (e.residual_f32) {
                         const float* rp = (const float*)e.residual + rrow * e.ldr + gcol;
                         pre_r[u] = *(const uint4*)rp; pre_r2[u] = *(const uint4*)(rp + 4);
                     } else {
@@ -365,7 +367,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             const bf16_t* p = (const bf16_t*)e.residual + rrow * e.ldr + gcol;
             float h[8];
             if (e.residual_f32) {
-                if (full) { *(uint4*)&h[0] = pre_r[u]; *(uint4*)&h[4] = pre_r2[u]; }
+                if (e.residual_f32 == 2) {
+                    if (full) unpack8_h(pre_r[u], h);
+                    else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? (float)((const _Float16*)e.residual)[rrow * e.ldr + gcol + x] : 0.f;
+                }
+                else if (full) { *(uint4*)&h[0] = pre_r[u]; *(uint4*)&h[4] = pre_r2[u]; }
                 else for (int x = 0; x < 8; ++x) h[x] = x < ncols ? ((const float*)e.residual)[rrow * e.ldr + gcol + x] : 0.f;
                 if (has_resln) {                          // the residual is a pre-LayerNorm row: add LayerNorm(row) (ln_fwd_kernel's arithmetic)
                     const long lrow = e.res_rowmap ? e.res_rowmap[grow] : grow;
@@ -392,6 +398,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* cl, int 
             bf16_t* p = (bf16_t*)g.C + (long)grow * out_rs + out_c0;      // row-major (ldc, gcol) or head-major (hm_head_dim, block base)
             if (full) *(uint4*)p = pack8(v);
             else for (int x = 0; x < ncols; ++x) p[x] = f2bf(v[x]);
+        } else if (e.out_mode == 3) {                      // fp16 store (the residual stream as halves)
+            _Float16* p = (_Float16*)g.C + (long)grow * g.ldc + gcol;
+            if (full) *(uint4*)p = pack8_h(v);
+            else for (int x = 0; x < ncols; ++x) p[x] = (_Float16)__builtin_amdgcn_fmed3f(v[x], -65504.f, 65504.f);
         } else if (!GEN || e.out_mode == 1) {
             float* p = (float*)g.C + (long)grow * g.ldc + gcol;
             if (full) { *(float4*)p = *(float4*)&v[0]; *(float4*)(p + 4) = *(float4*)&v[4]; }
@@ -1478,7 +1488,8 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     LAV_REQUIRE(g.e.hm_heads <= 0 || (g.e.out_mode == 0 && layout != 2 && splits == 1 && g.e.hm_head_dim > 0 && (g.e.hm_head_dim % 8) == 0 &&
                                       (N % (g.e.hm_heads * g.e.hm_head_dim)) == 0 && g.e.hm_rows >= M),
                 "lav_gemm_bf16: head-major store needs a bf16 output, layout 0 / 1, no split-K, hm_head_dim %% 8 == 0, N %% (hm_heads * hm_head_dim) == 0 and hm_rows >= M");
-    LAV_REQUIRE(g.e.out_mode == 0 || (ldc % 4) == 0, "lav_gemm_bf16: fp32 output needs ldc %% 4 == 0");
+    LAV_REQUIRE(g.e.out_mode == 0 || g.e.out_mode == 3 || (ldc % 4) == 0, "lav_gemm_bf16: fp32 output needs ldc %% 4 == 0");
+    LAV_REQUIRE(g.e.out_mode != 3 || ((ldc % 8) == 0 && layout != 2 && splits == 1), "lav_gemm_bf16: fp16 output needs ldc %% 8 == 0, layout 0 / 1, no split-K");
     int kps = ((K + splits - 1) / splits + BKT - 1) / BKT * BKT;
     g.k_per_split = kps;
     splits = (K + kps - 1) / kps;
@@ -1515,7 +1526,7 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
     if (g.e.row_scale) fm |= EF_RSCALE;
     if (g.e.residual) fm |= EF_RES;
     if (g.e.colsum) fm |= EF_COLSUM;
-    if (g.e.out_mode == 1) fm |= EF_O32;
+    if (g.e.out_mode == 1 || g.e.out_mode == 3) fm |= EF_O32;       // EF_O32 = 'not a bf16 store': fp32 or fp16 rows, told apart at run time
     if (g.e.out_mode == 2 || (N % 8) != 0) fm |= EF_GENERIC;
     constexpr unsigned S_B = EF_BIAS, S_BG = EF_BIAS | EF_ACT, S_GC = EF_GIN | EF_RSCALE | EF_COLSUM,
                        S_BDR = EF_BIAS | EF_DROP | EF_RSCALE | EF_RES, S_BDRO = S_BDR | EF_O32;

@@ -27,14 +27,15 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-// 8 consecutive elements of a bf16 or fp32 row
+// 8 consecutive elements of a 16-bit (bf16, or fp16 when `h16`: the fusion encoder's residual stream as halves) or fp32 row
 template <bool F32>
-__device__ __forceinline__ void load8(const void* base, long off, float* v) {
+__device__ __forceinline__ void load8(const void* base, long off, float* v, bool h16 = false) {
     if (F32) {
         const float* p = (const float*)base + off;
         *(float4*)&v[0] = *(const float4*)p; *(float4*)&v[4] = *(const float4*)(p + 4);
     } else {
-        unpack8(*(const uint4*)((const bf16_t*)base + off), v);
+        const uint4 u = *(const uint4*)((const bf16_t*)base + off);
+        if (h16) unpack8_h(u, v); else unpack8(u, v);
     }
 }
 
@@ -42,7 +43,7 @@ template <int G, int ITERS, bool X32>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int C, const void* __restrict__ x, long ldx, LnGeom geo,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     float eps, bf16_t* __restrict__ y, long ldy, float* mean_out,
-                                                    float* rstd_out, float* __restrict__ y32, long ldy32) {
+                                                    float* rstd_out, float* __restrict__ y32, long ldy32, int x_h16) {
     const int tid = threadIdx.x, gl = tid % G;
     const int row = blockIdx.x * (256 / G) + tid / G;
     if (row >= rows) return;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int C, const void
     for (int it = 0; it < ITERS; ++it) {
         int col = (it * G + gl) * 8;
         if (col < C) {
-            load8<X32>(x, ln_src_off(geo, row, col, ldx), v[it]);
+            load8<X32>(x, ln_src_off(geo, row, col, ldx), v[it], x_h16 != 0);
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += v[it][k];
         } else {
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
                 if (col < a.C) {
                     float xv[8], dv[8];
                     if (X32) { *(uint4*)&xv[0] = xu[q][it]; *(uint4*)&xv[4] = xu2[q][it]; }
+                    else if (a.ex.x_f32 == 2) unpack8_h(xu[q][it], xv);
                     else unpack8(xu[q][it], xv);
                     unpack8(du[q][it], dv);
                     float4 g0 = *(const float4*)(a.gamma + col), g1 = *(const float4*)(a.gamma + col + 4);
@@ -395,7 +397,8 @@ extern "C" int lav_layernorm_fwd(void* stream, int rows, int C, const void* x, l
                                  const float* gamma, const float* beta, float eps, void* y, long ldy, float* mean,
                                  float* rstd, const lav_ln_f32* f32io) {
     LAV_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "lav_layernorm_fwd: rows=%d C=%d (C must be a multiple of 8)", rows, C);
-    const bool x32 = f32io && f32io->x_f32;
+    const bool x32 = f32io && f32io->x_f32 == 1;
+    const int x_h16 = f32io && f32io->x_f32 == 2;            // fp16 rows: the 16-bit instantiation with the half -> float unpack
     float* y32 = f32io ? (float*)f32io->y32 : nullptr;
     const long ldy32 = f32io ? f32io->ldy32 : 0;
     LAV_REQUIRE(x && (y || y32) && gamma && beta, "lav_layernorm_fwd: null pointer");
@@ -407,7 +410,7 @@ extern "C" int lav_layernorm_fwd(void* stream, int rows, int C, const void* x, l
     hipStream_t s = (hipStream_t)stream;
 #define K_(G_, I_, X_)                                                                                              \
     hipLaunchKernelGGL((ln_fwd_kernel<G_, I_, X_>), dim3((rows + 256 / G_ - 1) / (256 / G_)), dim3(256), 0, s, rows, C, \
-                       x, ldx, geo, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd, y32, ldy32);
+                       x, ldx, geo, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd, y32, ldy32, x_h16);
     LN_DISPATCH(K_, x32)
 #undef K_
     return lav_check_launch("lav_layernorm_fwd");
@@ -461,7 +464,7 @@ extern "C" int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, 
         if (!a.part) a.part = ln_workspace(stream, (size_t)3 * grid * C * sizeof(float));
     }
 #define K_(G_, I_, X_) hipLaunchKernelGGL((ln_bwd_kernel<G_, I_, X_>), dim3(grid), dim3(256), lds, s, a);
-    const bool x32 = a.ex.x_f32 != 0;
+    const bool x32 = a.ex.x_f32 == 1;                      // 2 = fp16 rows: the 16-bit instantiation, unpacked as halves (a.ex.x_f32 is read in the kernel)
     LN_DISPATCH(K_, x32)
 #undef K_
     if (defer) {

@@ -49,14 +49,14 @@ extern "C" int lav_bert_layer_fwd(void* stream, const lav_bert_layer_desc* d) {
     // pre1 = res + dropout(cx Wao^T + b), fp32
     {
         lav_gemm_epilogue e = epi0();
-        e.bias = d->b_ao; e.dropout_p = d->p_hidden; e.seed = d->seed1; e.out_mode = 1;
+        e.bias = d->b_ao; e.dropout_p = d->p_hidden; e.seed = d->seed1; e.out_mode = d->stream_f16 ? 3 : 1;
         if (resln) {
-            e.residual = d->res_pre; e.ldr = H; e.residual_f32 = 1;
+            e.residual = d->res_pre; e.ldr = H; e.residual_f32 = d->stream_f16 ? 2 : 1;
             e.res_ln_mean = d->res_mean; e.res_ln_rstd = d->res_rstd; e.res_ln_gamma = d->res_gamma; e.res_ln_beta = d->res_beta;
         } else { e.residual = d->x; e.ldr = H; e.residual_f32 = 0; }
         LAV_TRY(lav_gemm_bf16(stream, 0, R, H, H, d->cx, H, d->w_ao, H, d->pre1, H, &e, 1));
     }
-    lav_ln_f32 f32io; f32io.x_f32 = 1; f32io.y32 = nullptr; f32io.ldy32 = 0;
+    lav_ln_f32 f32io; f32io.x_f32 = d->stream_f16 ? 2 : 1; f32io.y32 = nullptr; f32io.ldy32 = 0;
     LAV_TRY(lav_layernorm_fwd(stream, R, H, d->pre1, H, nullptr, d->ln1_gamma, d->ln1_beta, d->ln_eps, d->x1, H, d->mean1, d->rstd1, &f32io));
     // h = gelu(x1 Wff1^T + b), GELU' kept for the backward
     {
@@ -67,8 +67,8 @@ extern "C" int lav_bert_layer_fwd(void* stream, const lav_bert_layer_desc* d) {
     // pre2 = LN1(pre1) + dropout(h Wff2^T + b), fp32: the LayerNorm output is recomputed from the saved pre-LN rows in the epilogue
     {
         lav_gemm_epilogue e = epi0();
-        e.bias = d->b_ff2; e.dropout_p = d->p_hidden; e.seed = d->seed2; e.out_mode = 1;
-        e.residual = d->pre1; e.ldr = H; e.residual_f32 = 1;
+        e.bias = d->b_ff2; e.dropout_p = d->p_hidden; e.seed = d->seed2; e.out_mode = d->stream_f16 ? 3 : 1;
+        e.residual = d->pre1; e.ldr = H; e.residual_f32 = d->stream_f16 ? 2 : 1;
         e.res_ln_mean = d->mean1; e.res_ln_rstd = d->rstd1; e.res_ln_gamma = d->ln1_gamma; e.res_ln_beta = d->ln1_beta;
         LAV_TRY(lav_gemm_bf16(stream, 0, R, H, F, d->h, F, d->w_ff2, F, d->pre2, H, &e, 1));
     }
@@ -112,7 +112,7 @@ extern "C" int lav_bert_layer_bwd(void* stream, void* side_stream, const lav_ber
     // y = LN2(pre2), pre2 = x1 + dropout(dense(h)): d_pre2 (residual branch) and d_dense2 = dropout'(d_pre2) (+ its column sums = bias gradient)
     {
         lav_ln_bwd_extra ex; memset(&ex, 0, sizeof(ex));
-        ex.dx2 = b->d_dense2; ex.lddx2 = H; ex.rows_per_group = 1; ex.dropout_p = d->p_hidden; ex.seed = d->seed2; ex.colsum = b->g_b_ff2; ex.x_f32 = 1;
+        ex.dx2 = b->d_dense2; ex.lddx2 = H; ex.rows_per_group = 1; ex.dropout_p = d->p_hidden; ex.seed = d->seed2; ex.colsum = b->g_b_ff2; ex.x_f32 = d->stream_f16 ? 2 : 1;
         LAV_TRY(lav_layernorm_bwd(stream, R, H, b->dy, H, d->pre2, H, nullptr, d->ln2_gamma, d->mean2, d->rstd2, nullptr, 0, b->d_pre2, H,
                                   b->g_ln2_gamma, b->g_ln2_beta, &ex));
     }
@@ -131,7 +131,7 @@ extern "C" int lav_bert_layer_bwd(void* stream, void* side_stream, const lav_ber
     // x1 = LN1(pre1), pre1 = x + dropout(dense(cx))
     {
         lav_ln_bwd_extra ex; memset(&ex, 0, sizeof(ex));
-        ex.dx2 = b->d_dense1; ex.lddx2 = H; ex.rows_per_group = 1; ex.dropout_p = d->p_hidden; ex.seed = d->seed1; ex.colsum = b->g_b_ao; ex.x_f32 = 1;
+        ex.dx2 = b->d_dense1; ex.lddx2 = H; ex.rows_per_group = 1; ex.dropout_p = d->p_hidden; ex.seed = d->seed1; ex.colsum = b->g_b_ao; ex.x_f32 = d->stream_f16 ? 2 : 1;
         LAV_TRY(lav_layernorm_bwd(stream, R, H, b->d_x1, H, d->pre1, H, nullptr, d->ln1_gamma, d->mean1, d->rstd1, nullptr, 0, b->d_pre1, H,
                                   b->g_ln1_gamma, b->g_ln1_beta, &ex));
     }

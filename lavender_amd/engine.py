@@ -53,6 +53,12 @@ _DW_PRIORITY = int(os.environ.get("LAV_DW_PRIORITY", "0"))      # probe hook: HI
 # injected (tests/bf16_error_budget.py): this halves the logit error of the full-width model (mean 5.5e-3 -> 2.5e-3, max
 # 3.6e-2 -> 1.6e-2); the same change on the pre-LN Swin stream changes nothing, so the video side stays bf16.
 STREAM32 = os.environ.get("LAV_STREAM32", "1") != "0"
+# Late round 4: that wide stream is stored as fp16 rows, not fp32 -- 11 mantissa bits against bf16's 8 keep the logit error where the fp32
+# stream had it (oracle with the rounding injected, Swin-B + 12 layers: mean |d| 2.65e-3 / max 1.72e-2 with an fp16 stream, 2.56e-3 / 1.64e-2
+# with fp32, 5.49e-3 / 3.55e-2 with bf16) at half the bytes: 69 instead of 138 MB per pre-LayerNorm tensor at the cfg2 shape, read three
+# times and written once per LayerNorm.  Stores saturate at +-65504.  LAV_STREAM_DTYPE=fp32 restores fp32 rows (the reference itself ran
+# fp16 autocast, utils/deepspeed.py:20-51).
+STREAM_DT = torch.float32 if os.environ.get("LAV_STREAM_DTYPE", "fp16") == "fp32" else torch.float16
 # The fp32 copy of a LayerNorm output only ever feeds the NEXT residual add, so it is not written: that GEMM epilogue takes the
 # saved pre-LayerNorm rows + (mean, rstd, gamma, beta) and adds LayerNorm(rows) itself (lav_gemm_epilogue.res_ln_*; same
 # arithmetic, same bits).  138 MB less written per LayerNorm at the cfg2 shape.  LAV_RESLN=0 restores the fp32 LayerNorm output.
@@ -604,7 +610,7 @@ class BertLayerFn(torch.autograd.Function):
         rowmap = pair[0] if pair is not None else None
         assert pair is not None or x.shape[0] == R
         f32 = torch.float32
-        sdt = f32 if STREAM32 else bf16
+        sdt = STREAM_DT if STREAM32 else bf16
         heads = layer.num_heads
         arena = layer._arena()
         att_m = layer.attention.self
@@ -683,7 +689,7 @@ class BertLayerFn(torch.autograd.Function):
         e = torch.empty
         qkv, cx, x1, h, y = e((R, 3 * Hd), dtype=bf16, device=dev), e((R, Hd), dtype=bf16, device=dev), e((R, Hd), dtype=bf16, device=dev), \
             e((R, F), dtype=bf16, device=dev), e((R, Hd), dtype=bf16, device=dev)
-        pre1, pre2 = e((R, Hd), dtype=f32, device=dev), e((R, Hd), dtype=f32, device=dev)
+        pre1, pre2 = e((R, Hd), dtype=STREAM_DT, device=dev), e((R, Hd), dtype=STREAM_DT, device=dev)
         st1, st2 = e((2, R), dtype=f32, device=dev), e((2, R), dtype=f32, device=dev)          # (mean, rstd) of the two LayerNorms
         lse = h_pre = None
         if keep:
@@ -698,7 +704,7 @@ class BertLayerFn(torch.autograd.Function):
         fields = (n, L, Hd, c["heads"], F, float(p_hidden), float(p_attn), c["eps"], s_att, s1, s2, int(causal_from),
                   K._dp(key_mask)) + c["params"] + (x.data_ptr(),) + res + (
                   qkv.data_ptr(), cx.data_ptr(), K._dp(lse), pre1.data_ptr(), p1, p1 + 4 * R, x1.data_ptr(), K._dp(h_pre), h.data_ptr(),
-                  pre2.data_ptr(), p2, p2 + 4 * R, y.data_ptr())
+                  pre2.data_ptr(), p2, p2 + 4 * R, y.data_ptr(), int(STREAM_DT == torch.float16))
         K.bert_layer_fwd(fields)
         mean2, rstd2 = st2[0], st2[1]
         if keep:

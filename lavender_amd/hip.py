@@ -83,9 +83,9 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
         out = torch.empty((M, ldc), dtype=out_dtype, device=A.device)
     else:
         ldc = _ld(out)
-    res32 = residual is not None and residual.dtype == torch.float32
+    res32 = 0 if residual is None else (1 if residual.dtype == torch.float32 else (2 if residual.dtype == torch.float16 else 0))   # lav_gemm_epilogue.residual_f32
     if res_ln is not None:
-        assert res32 and out.dtype == torch.float32
+        assert res32 and out.dtype in (torch.float32, torch.float16)
         ln_m, ln_r, ln_g, ln_b = (t.data_ptr() for t in res_ln)
     else:
         ln_m = ln_r = ln_g = ln_b = 0
@@ -96,7 +96,7 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
                         _dp(gelu_in), _ld(gelu_in) if gelu_in is not None else 0,
                         float(dropout_p), int(seed) & 0xFFFFFFFF, _dp(row_scale), int(rows_per_group),
                         _dp(residual), _ld(residual) if residual is not None else 0, _dp(colsum), float(alpha),
-                        2 if accumulate else (1 if out.dtype == torch.float32 else 0),
+                        2 if accumulate else (1 if out.dtype == torch.float32 else (3 if out.dtype == torch.float16 else 0)),
                         _dp(k_keep), int(k_rows_per_group), _dp(rowsum_a), int(preact_is_grad), int(gelu_in_is_grad), int(res32),
                         _dp(a_rowmap), _dp(res_rowmap), ln_m, ln_r, ln_g, ln_b, hm_h, hm_d, hm_rows, int(bool(c_pad_writable)))
     rc = L.lib.lav_gemm_bf16(_s(), layout, M, N, K, A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), out.data_ptr(), ldc, ref, splits)
@@ -106,8 +106,8 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
 
 
 # ---- stage-level entries (lavender_amd/csrc/stages.cpp): one C call per fusion-encoder layer pass ------------------------------------
-_BL_FWD_PACK = _struct.Struct("@5i3f3Ii32P")
-_BL_BWD_PACK = _struct.Struct("@5i3f3Ii32P5P4q12P4i9P")
+_BL_FWD_PACK = _struct.Struct("@5i3f3Ii32Pi4x")
+_BL_BWD_PACK = _struct.Struct("@5i3f3Ii32Pi5P4q12P4i9P")
 assert _BL_FWD_PACK.size == C.sizeof(L.BertLayerDesc) and _BL_BWD_PACK.size == C.sizeof(L.BertLayerBwdDesc)
 
 
@@ -150,7 +150,7 @@ def swin_block_bwd(fields, side_stream):
 
 
 def bert_layer_fwd(fields):
-    """fields: the 44 values of lav_bert_layer_desc in declaration order (ints / floats / device addresses, 0 = NULL)."""
+    """fields: the 45 values of lav_bert_layer_desc in declaration order (ints / floats / device addresses, 0 = NULL)."""
     rf, pf, _, _ = _stage_buffers()
     _BL_FWD_PACK.pack_into(rf, 0, *fields)
     rc = L.lib.lav_bert_layer_fwd(_s(), pf)
@@ -159,7 +159,7 @@ def bert_layer_fwd(fields):
 
 
 def bert_layer_bwd(fields, side_stream):
-    """fields: lav_bert_layer_bwd_desc in declaration order (the forward's 44 values first); side_stream: raw hipStream_t or None."""
+    """fields: lav_bert_layer_bwd_desc in declaration order (the forward's 45 values first); side_stream: raw hipStream_t or None."""
     _, _, rb, pb = _stage_buffers()
     _BL_BWD_PACK.pack_into(rb, 0, *fields)
     rc = L.lib.lav_bert_layer_bwd(_s(), side_stream, pb)
@@ -212,16 +212,16 @@ def _gather(g):
 
 
 def layernorm_fwd(x, rows, Cn, gamma, beta, eps, gather=None, out=None, want_stats=True, out32=None, want16=True):
-    """x bf16 or fp32 (the fp32 residual stream); out32: optional fp32 copy of the output (then returned 4th)."""
+    """x bf16, fp32 or fp16 (the wide residual stream of the fusion encoder); out32: optional fp32 copy of the output (then returned 4th)."""
     dev = x.device
     y = out if out is not None else (torch.empty((rows, Cn), dtype=bf16, device=dev) if want16 else None)
     mean = torch.empty(rows, dtype=torch.float32, device=dev) if want_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=dev) if want_stats else None
     ldx = gather[2] if gather is not None else _ld(x)
     f = None
-    if x.dtype == torch.float32 or out32 is not None:
+    if x.dtype in (torch.float32, torch.float16) or out32 is not None:
         st = L.LnF32()
-        st.x_f32 = int(x.dtype == torch.float32)
+        st.x_f32 = 1 if x.dtype == torch.float32 else (2 if x.dtype == torch.float16 else 0)
         st.y32 = _p(out32)
         st.ldy32 = _ld(out32) if out32 is not None else 0
         f = C.byref(st)
@@ -254,7 +254,7 @@ def layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dgamma, dbeta, gather=None
     ldx = gather[2] if gather is not None else _ld(x)
     lddx = gather[2] if gather is not None else _ld(dx)
     ex = None
-    x32 = x.dtype == torch.float32
+    x32 = 1 if x.dtype == torch.float32 else (2 if x.dtype == torch.float16 else 0)      # lav_ln_bwd_extra.x_f32
     if dx2 is not None or colsum is not None or x32 or finish_stream is not None:
         s = L.LnBwdExtra()
         s.finish_stream = finish_stream.cuda_stream if finish_stream is not None else None

@@ -343,6 +343,46 @@ def test_gemm_ragged_vocab_with_writable_padding():
     assert torch.equal(ref[:, :V], buf[:, :V]) and (ref[:, V:] == 7.0).all()
 
 
+def test_fp16_rows_of_the_residual_stream_gemm_and_layernorm():
+    """The fusion encoder's wide residual stream as fp16 rows (lav_gemm_epilogue.out_mode 3 / residual_f32 2, lav_ln_f32.x_f32 2,
+    lav_ln_bwd_extra.x_f32 2).  With values that are exactly representable as halves, every kernel must give the SAME bits as with the fp32
+    rows: the GEMM epilogue that adds LayerNorm(residual) recomputed from saved pre-LN rows, its fp16 store against the rounded fp32 store,
+    LayerNorm forward (statistics included) and backward (dx, dx2, dgamma, dbeta, colsum).  Plus: the store saturates instead of overflowing."""
+    M, N, Kd = 4512, 768, 768
+    A, Wt = rb(M, Kd, scale=0.5), rb(N, Kd, scale=0.05, seed=1)
+    bias = (0.1 * torch.randn(N, generator=torch.Generator().manual_seed(3))).cuda()
+    pre32 = (2.0 * torch.randn(M, N, generator=torch.Generator().manual_seed(4))).half().float().cuda()      # halves, held as fp32
+    pre16 = pre32.half()
+    g = (1.0 + 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(5))).cuda()
+    b = (0.1 * torch.randn(N, generator=torch.Generator().manual_seed(6))).cuda()
+    # LayerNorm forward on the two row types
+    y32, m32, r32 = K().layernorm_fwd(pre32, M, N, g, b, 1e-12)
+    y16, m16, r16 = K().layernorm_fwd(pre16, M, N, g, b, 1e-12)
+    assert torch.equal(y32, y16) and torch.equal(m32, m16) and torch.equal(r32, r16)
+    # GEMM: bias + dropout + residual = LayerNorm(pre) recomputed in the epilogue, fp32 rows in / fp32 out  vs  fp16 rows in / fp16 out
+    o32 = K().gemm(0, A, Wt, M, N, Kd, bias=bias, dropout_p=0.1, seed=9, residual=pre32, res_ln=(m32, r32, g, b), out_dtype=torch.float32)
+    o16 = K().gemm(0, A, Wt, M, N, Kd, bias=bias, dropout_p=0.1, seed=9, residual=pre16, res_ln=(m16, r16, g, b), out_dtype=torch.float16)
+    assert o16.dtype == torch.float16 and torch.equal(o32.half(), o16)
+    # plain residual add (no LayerNorm recompute) and the 128 x 128 kernel (small M)
+    o32 = K().gemm(0, A[:300], Wt, 300, N, Kd, bias=bias, residual=pre32[:300], out_dtype=torch.float32)
+    o16 = K().gemm(0, A[:300], Wt, 300, N, Kd, bias=bias, residual=pre16[:300], out_dtype=torch.float16)
+    assert torch.equal(o32.half(), o16)
+    # saturation instead of infinity
+    big = K().gemm(0, (A * 0 + 200).to(bf16), (Wt * 0 + 1).to(bf16), M, N, Kd, out_dtype=torch.float16)      # 200 * 768 = 153600 > 65504
+    assert torch.isfinite(big.float()).all() and (big.float() == 65504.0).all()
+    # LayerNorm backward
+    dy = rb(M, N, seed=11)
+    outs = []
+    for x in (pre32, pre16):
+        dg, db, cs = (torch.zeros(N, device="cuda") for _ in range(3))
+        dx2 = torch.empty(M, N, dtype=bf16, device="cuda")
+        dx = K().layernorm_bwd(dy, x, M, N, g, m32, r32, dg, db, dx2=dx2, dropout_p=0.1, seed=13, colsum=cs)
+        torch.cuda.synchronize()
+        outs.append((dx, dx2, dg, db, cs))
+    for u, v, what in zip(outs[0], outs[1], ("dx", "dx2", "dgamma", "dbeta", "colsum")):
+        assert torch.equal(u, v), f"LayerNorm backward on fp16 rows: {what} differs from the fp32-row result"
+
+
 def test_layernorm_bwd_deferred_column_reductions_match_immediate_ones():
     """lav_layernorm_set_defer / lav_layernorm_flush: the row pass queues the reduction of its per-block column partials and ONE launch per
     flush completes all of them.  60 backward calls on three shapes (more than the 48-entry job table: the 49th call flushes by itself),

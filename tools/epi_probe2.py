@@ -31,5 +31,17 @@ rows = [
     ("ff2   +bias+res(fp32)->fp32 (no dropout)", lambda: K.gemm(0, h, W2, R, H, F, out=o_32, bias=b2, residual=pre32)),
     ("ff2   +bias+res(bf16)->bf16", lambda: K.gemm(0, h, W2, R, H, F, out=o_b, bias=b2, residual=x)),
 ]
+pre16 = pre32.half(); o_16 = torch.empty(R, H, device=dev, dtype=torch.float16)
+rows += [
+    ("ao    +bias+drop+res(fp16 pre-LN, LN recomputed)->fp16", lambda: K.gemm(0, x, Wa, R, H, H, out=o_16, bias=ba, dropout_p=0.1, seed=3, residual=pre16, res_ln=(mean, rstd, g, b))),
+    ("ff2   +bias+drop+res(fp16 pre-LN, LN recomputed)->fp16", lambda: K.gemm(0, h, W2, R, H, F, out=o_16, bias=b2, dropout_p=0.1, seed=3, residual=pre16, res_ln=(mean, rstd, g, b))),
+    ("LayerNorm fwd, fp32 rows -> bf16", lambda: K.layernorm_fwd(pre32, R, H, g, b, 1e-12)),
+    ("LayerNorm fwd, fp16 rows -> bf16", lambda: K.layernorm_fwd(pre16, R, H, g, b, 1e-12)),
+]
+dyb = torch.randn(R, H, device=dev).to(bf); dgz, dbz, csz = (torch.zeros(H, device=dev) for _ in range(3)); dx2 = torch.empty(R, H, device=dev, dtype=bf)
+rows += [
+    ("LayerNorm bwd (+dx2, dropout, colsum), fp32 rows", lambda: K.layernorm_bwd(dyb, pre32, R, H, g, mean, rstd, dgz, dbz, dx2=dx2, dropout_p=0.1, seed=5, colsum=csz)),
+    ("LayerNorm bwd (+dx2, dropout, colsum), fp16 rows", lambda: K.layernorm_bwd(dyb, pre16, R, H, g, mean, rstd, dgz, dbz, dx2=dx2, dropout_p=0.1, seed=5, colsum=csz)),
+]
 for name, f in rows:
     print(f"{name:62s} {bench(f, n=20):7.1f} us", flush=True)
