@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 const char* lav_last_error(void);
-int lav_abi_version(void);   /* 5: fp16 rows (out_mode 3, residual_f32 / x_f32 = 2, lav_bert_layer_desc.stream_f16), lav_layernorm_set_defer / lav_layernorm_flush, lav_attn_desc.bias_map / lav_attention_build_bias_map; 4: lav_gemm_epilogue.c_pad_writable; 3: a_rowmap / res_rowmap / res_ln_*; 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
+int lav_abi_version(void);   /* 5: lav_gemm_tn_grouped (+ lav_*_bwd_desc.group_splits), fp16 rows (out_mode 3, residual_f32 / x_f32 = 2, lav_bert_layer_desc.stream_f16), lav_layernorm_set_defer / lav_layernorm_flush, lav_attn_desc.bias_map / lav_attention_build_bias_map; 4: lav_gemm_epilogue.c_pad_writable; 3: a_rowmap / res_rowmap / res_ln_*; 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM with fused epilogue.  Replaces every nn.Linear on the path (video_swin.py:73-79,137-139,
@@ -94,6 +94,25 @@ typedef struct lav_gemm_epilogue {
 
 int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                   void* C, long ldc, const lav_gemm_epilogue* epi, int splits);
+/* Grouped weight gradients: C_j[M_j, N_j] (fp32) += alpha_j * A_j[K_j, M_j]^T . B_j[K_j, N_j] for 1 ... 4 independent jobs in ONE launch -- the
+ * four nn.Linear weight gradients of a Swin block (video_swin.py:73-79,137-139,168) or of a fusion layer (HF BertLayer).  One by one each of
+ * them needs 8 ... 32 split-K parts to fill the machine; together their tiles need `splits` = 1 ... 3.  rowsum_a (fp32 [M_j], += alpha * column
+ * sums of A: the bias gradient) and k_keep / k_rows_per_group (stochastic depth: contraction rows of dropped samples are skipped) as in
+ * lav_gemm_epilogue.  Jobs that do not fit the 256 x 256 weight-gradient kernel (M_j >= 160, N_j % 256 == 0, K_j % 32 == 0) make the call run
+ * every job through lav_gemm_bf16(layout 2) with its own fallback_splits instead: same results up to fp32 summation order. */
+typedef struct lav_gemm_tn_job {
+    int M, N, K;
+    const void* A; long lda;      /* bf16 [K, lda >= M] */
+    const void* B; long ldb;      /* bf16 [K, ldb >= N] */
+    float* C; long ldc;           /* fp32 [M, ldc >= N], accumulated */
+    float* rowsum_a;              /* or NULL */
+    const float* k_keep;          /* or NULL */
+    int k_rows_per_group;
+    float alpha;                  /* 0 is read as 1 */
+    int fallback_splits;
+} lav_gemm_tn_job;
+int lav_gemm_tn_grouped(void* stream, int n_jobs, const lav_gemm_tn_job* jobs, int splits);
+
 /* Tuning / probe hook: selects between kernel variants at run time (within-process A/B measurements in tools/): which 2 = ping-pong
  * weight-gradient kernel on/off, 5 = probe bits of the 256x256 kernel (timing only, wrong results), 6 = column-group width of the tile
  * walk, 7 / 9 = 192-row tiles / their loader-wave form on/off.  Returns the previous value, -1 for
@@ -408,6 +427,8 @@ typedef struct lav_bert_layer_bwd_desc {
     /* temporaries (bf16) and the result */
     void* d_pre2; void* d_dense2; void* dh; void* d_x1; void* d_pre1; void* d_dense1; void* d_cx; void* dqkv;
     void* dx;                                              /* bf16 (rows, hidden) */
+    int group_splits;                                      /* > 0: the four weight-gradient GEMMs run as ONE grouped launch (lav_gemm_tn_grouped) with this split
+                                                              factor, issued when the last of their operands (dqkv) exists; splits_* are then the fallback factors */
 } lav_bert_layer_bwd_desc;
 int lav_bert_layer_bwd(void* stream, void* side_stream, const lav_bert_layer_bwd_desc* d);
 
@@ -443,6 +464,7 @@ typedef struct lav_swin_block_bwd_desc {
     int splits_qkv, splits_proj, splits_fc1, splits_fc2;
     void* dh; void* d_y2; void* d_mid; void* d_ao; void* dqkv; void* d_y1;     /* temporaries, bf16 */
     void* dx;                                              /* bf16 (rows, C) */
+    int group_splits;                                      /* as lav_bert_layer_bwd_desc.group_splits */
 } lav_swin_block_bwd_desc;
 /* side_stream as in lav_bert_layer_bwd; the relative-position-bias-table gradient runs there too when lav_attention_bias_split(attn). */
 int lav_swin_block_bwd(void* stream, void* side_stream, const lav_swin_block_bwd_desc* d);

@@ -33,6 +33,11 @@ class GemmEpilogue(C.Structure):
                 ("res_ln_mean", vp), ("res_ln_rstd", vp), ("res_ln_gamma", vp), ("res_ln_beta", vp), ("hm_heads", i32), ("hm_head_dim", i32), ("hm_rows", i64), ("c_pad_writable", i32)]
 
 
+class GemmTnJob(C.Structure):             # struct lav_gemm_tn_job
+    _fields_ = [("M", i32), ("N", i32), ("K", i32), ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64),
+                ("rowsum_a", vp), ("k_keep", vp), ("k_rows_per_group", i32), ("alpha", f32), ("fallback_splits", i32)]
+
+
 class LnGather(C.Structure):
     _fields_ = [("mode", i32), ("H", i32), ("W", i32), ("C0", i32)]
 
@@ -68,7 +73,7 @@ class BertLayerBwdDesc(C.Structure):       # struct lav_bert_layer_bwd_desc
                 [(n, vp) for n in ("g_w_qkv", "g_b_qkv", "g_w_ao", "g_b_ao", "g_ln1_gamma", "g_ln1_beta", "g_w_ff1", "g_b_ff1", "g_w_ff2", "g_b_ff2",
                                    "g_ln2_gamma", "g_ln2_beta")] +
                 [(n, i32) for n in ("splits_qkv", "splits_ao", "splits_ff1", "splits_ff2")] +
-                [(n, vp) for n in ("d_pre2", "d_dense2", "dh", "d_x1", "d_pre1", "d_dense1", "d_cx", "dqkv", "dx")])
+                [(n, vp) for n in ("d_pre2", "d_dense2", "dh", "d_x1", "d_pre1", "d_dense1", "d_cx", "dqkv", "dx")] + [("group_splits", i32)])
 
 
 class SwinBlockDesc(C.Structure):          # struct lav_swin_block_desc
@@ -84,7 +89,7 @@ class SwinBlockBwdDesc(C.Structure):       # struct lav_swin_block_bwd_desc
                 [(n, vp) for n in ("g_ln1_gamma", "g_ln1_beta", "g_w_qkv", "g_b_qkv", "g_bias_table", "g_w_proj", "g_b_proj", "g_ln2_gamma", "g_ln2_beta",
                                    "g_w_fc1", "g_b_fc1", "g_w_fc2", "g_b_fc2")] +
                 [(n, i32) for n in ("splits_qkv", "splits_proj", "splits_fc1", "splits_fc2")] +
-                [(n, vp) for n in ("dh", "d_y2", "d_mid", "d_ao", "dqkv", "d_y1", "dx")])
+                [(n, vp) for n in ("dh", "d_y2", "d_mid", "d_ao", "dqkv", "d_y1", "dx")] + [("group_splits", i32)])
 
 
 P = C.POINTER
@@ -93,6 +98,7 @@ _SIGS = {
     "lav_abi_version": (i32, []),
     "lav_gemm_bf16": (i32, [vp, i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, P(GemmEpilogue), i32]),
     "lav_gemm_select": (i32, [i32, i32]),
+    "lav_gemm_tn_grouped": (i32, [vp, i32, P(GemmTnJob), i32]),
     "lav_bert_layer_fwd": (i32, [vp, P(BertLayerDesc)]),
     "lav_bert_layer_bwd": (i32, [vp, vp, P(BertLayerBwdDesc)]),
     "lav_swin_block_fwd": (i32, [vp, P(SwinBlockDesc)]),

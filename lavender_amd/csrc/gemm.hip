@@ -1135,7 +1135,7 @@ __device__ __forceinline__ void pp_wait_tiles(int rem) {   // s_waitcnt vmcnt(4 
 }
 
 template <bool TN, unsigned F, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int bid_in) {
     static_assert(TN && F == EF_TNFLUSH && DBG == 0, "ping-pong kernel: weight-gradient layout only (the K-contiguous form was removed in round 4)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     const int grp = wave >> 2, wn = wave & 3;
     const int tiles_n = (g.N + 255) / 256, tiles_m = (g.M + BIG_BM - 1) / BIG_BM;
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
+    int bid = bid_in;
     {
         const int tot = nwg * g.splits;
         int q = tot >> 3, r = tot & 7, xcd = bid & 7, idx = bid >> 3;
@@ -1365,6 +1365,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             __syncthreads();
         }
     }
+}
+
+template <bool TN, unsigned F, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) { gemm_pp_body<TN, F, DBG>(g, (int)blockIdx.x); }
+
+// GROUPED weight gradients (lav_gemm_tn_grouped): up to four independent C_j += A_j^T B_j products in ONE launch -- the four weight
+// gradients of a Swin block / a fusion layer.  Launched one by one each of them needs 8-32 split-K parts to put ~128 workgroups on the
+// machine (partial tiles through the fp32 workspace, a reduction pass each, k-loops of 15-40 steps); together their 26-108 tiles need 1-3
+// parts.  Block b belongs to the job whose first block is the largest blk0 <= b; the job is selected by an if-chain over CONSTANT
+// indices so that every copy of the body reads its GemmArgs straight from the kernel arguments (a run-time index would make the compiler
+// copy the 1.6 KB table to scratch).
+struct GemmGroup { int n; int blk0[4]; GemmArgs g[4]; };
+template <bool TN, unsigned F>
+__global__ __launch_bounds__(512) void gemm_pp_group_kernel(GemmGroup G) {
+    const int b = (int)blockIdx.x;
+    if (G.n > 3 && b >= G.blk0[3]) gemm_pp_body<TN, F>(G.g[3], b - G.blk0[3]);
+    else if (G.n > 2 && b >= G.blk0[2]) gemm_pp_body<TN, F>(G.g[2], b - G.blk0[2]);
+    else if (G.n > 1 && b >= G.blk0[1]) gemm_pp_body<TN, F>(G.g[1], b - G.blk0[1]);
+    else gemm_pp_body<TN, F>(G.g[0], b);
 }
 
 // ---- split-K reduction: C[r][c] += sum_s ws[s][tile(r,c)][r % 128][c % 128] -------------------------------------
@@ -1694,4 +1713,76 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         }
     }
     return lav_check_launch("lav_gemm_bf16");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Grouped weight gradients: C_j (fp32, accumulated) += alpha_j * A_j^T B_j for up to four jobs in one launch of the ping-pong kernel.
+// Every job must fit that kernel (>= 160 output rows (256 below 512 columns), N % 256 == 0, K % 32 == 0, the drop-path row rule);
+// otherwise -- or with LAV_GEMM_TN_GROUP=0 -- the jobs run one by one through lav_gemm_bf16 with their own fallback split factors.
+// ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" int lav_gemm_tn_grouped(void* stream, int n_jobs, const lav_gemm_tn_job* jobs, int splits) {
+    LAV_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 4, "lav_gemm_tn_grouped: 1 ... 4 jobs (got %d)", n_jobs);
+    static const bool group_on = getenv("LAV_GEMM_TN_GROUP") ? atoi(getenv("LAV_GEMM_TN_GROUP")) != 0 : true;
+    static const int tn_min_m_env = getenv("LAV_GEMM_TN_MINM") ? atoi(getenv("LAV_GEMM_TN_MINM")) : 160;
+    if (splits < 1) splits = 1;
+    bool ok = group_on && lav_gemm_pp_tn && lav_gemm_tn_kind != 0 && lav_gemm_tn_kind != 1;
+    for (int j = 0; j < n_jobs && ok; ++j) {
+        const lav_gemm_tn_job& q = jobs[j];
+        const int tn_min_m = q.N >= 512 ? tn_min_m_env : (tn_min_m_env > 256 ? tn_min_m_env : 256);
+        ok = q.A && q.B && q.C && q.M >= tn_min_m && q.N > 0 && (q.N % 256) == 0 && q.K >= PP_BK && (q.K % PP_BK) == 0 && (q.lda % 8) == 0 && (q.ldb % 8) == 0 &&
+             (q.ldc % 4) == 0 && (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15) == 0 &&
+             (!q.k_keep || (q.k_rows_per_group >= BKT && (q.K + q.k_rows_per_group - 1) / q.k_rows_per_group <= 128));
+    }
+    if (!ok) {
+        for (int j = 0; j < n_jobs; ++j) {
+            const lav_gemm_tn_job& q = jobs[j];
+            lav_gemm_epilogue e;
+            memset(&e, 0, sizeof(e));
+            e.alpha = q.alpha == 0.f ? 1.f : q.alpha; e.rows_per_group = 1; e.out_mode = 2; e.rowsum_a = q.rowsum_a; e.k_keep = q.k_keep;
+            e.k_rows_per_group = q.k_keep ? q.k_rows_per_group : 1;
+            if (int rc = lav_gemm_bf16(stream, 2, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, &e, q.fallback_splits > 0 ? q.fallback_splits : 1)) return rc;
+        }
+        return LAV_OK;
+    }
+    GemmGroup G;
+    memset(&G, 0, sizeof(G));
+    G.n = n_jobs;
+    size_t ws_off[4] = {0, 0, 0, 0}, ws_bytes = 0;
+    int ws_tiles[4] = {0, 0, 0, 0}, blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const lav_gemm_tn_job& q = jobs[j];
+        GemmArgs& g = G.g[j];
+        g.A = (const bf16_t*)q.A; g.B = (const bf16_t*)q.B; g.C = q.C; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.M = q.M; g.N = q.N; g.K = q.K;
+        g.e.alpha = q.alpha == 0.f ? 1.f : q.alpha; g.e.rows_per_group = 1; g.e.out_mode = 2; g.e.rowsum_a = q.rowsum_a; g.e.k_keep = q.k_keep;
+        g.e.k_rows_per_group = q.k_keep ? q.k_rows_per_group : 1;
+        int sp = splits;
+        if (sp > q.K / 256) sp = q.K / 256 > 0 ? q.K / 256 : 1;
+        const int kps = ((q.K + sp - 1) / sp + BKT - 1) / BKT * BKT;
+        g.k_per_split = kps;
+        g.splits = (q.K + kps - 1) / kps;
+        ws_tiles[j] = ((q.M + BIG_BM - 1) / BIG_BM) * ((q.N + BN - 1) / BN);
+        if (g.splits == 1) g.owner = 1;
+        else { ws_off[j] = ws_bytes; ws_bytes += (size_t)g.splits * ws_tiles[j] * BIG_BM * BN * sizeof(float); }
+        G.blk0[j] = blocks;
+        blocks += ((q.M + BIG_BM - 1) / BIG_BM) * (q.N / 256) * g.splits;
+    }
+    if (ws_bytes) {
+        float* ws = splitk_workspace(stream, ws_bytes);
+        LAV_REQUIRE(ws, "lav_gemm_tn_grouped: split-K workspace allocation failed");
+        for (int j = 0; j < n_jobs; ++j)
+            if (G.g[j].splits > 1) { G.g[j].ws = (float*)((char*)ws + ws_off[j]); G.g[j].ws_tiles = ws_tiles[j]; }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)gemm_pp_group_kernel<true, EF_TNFLUSH>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS); (void)hipGetLastError(); attr = true; }
+    hipLaunchKernelGGL((gemm_pp_group_kernel<true, EF_TNFLUSH>), dim3(blocks), dim3(512), PP_LDS, s, G);
+    for (int j = 0; j < n_jobs; ++j) {
+        const GemmArgs& g = G.g[j];
+        if (g.splits > 1) {
+            const long n = (long)g.M * (g.N / 4);
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, g.ws, g.splits, ws_tiles[j], (g.N + BN - 1) / BN, BIG_BM, g.M, g.N,
+                               (float*)g.C, g.ldc);
+        }
+    }
+    return lav_check_launch("lav_gemm_tn_grouped");
 }

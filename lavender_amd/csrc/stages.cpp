@@ -5,6 +5,7 @@
 #include "common.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../include/lavender_hip.h"
 
 #define LAV_TRY(call) do { const int rc_ = (call); if (rc_ != LAV_OK) return rc_; } while (0)
@@ -101,6 +102,15 @@ static int dw_gemm(hipStream_t main_s, hipStream_t side_s, int M, int N, int K, 
     return lav_gemm_bf16(side_s, 2, M, N, K, A, M, B, N, out, N, &e, splits);
 }
 
+static lav_gemm_tn_job tn_job(int M, int N, int K, const void* A, const void* B, float* out, int fallback_splits, float* rowsum, const float* keep = nullptr,
+                              int rows_per_group = 1, float alpha = 1.f) {
+    lav_gemm_tn_job q;
+    memset(&q, 0, sizeof(q));
+    q.M = M; q.N = N; q.K = K; q.A = A; q.lda = M; q.B = B; q.ldb = N; q.C = out; q.ldc = N; q.rowsum_a = rowsum; q.k_keep = keep;
+    q.k_rows_per_group = keep ? rows_per_group : 1; q.alpha = keep ? alpha : 1.f; q.fallback_splits = fallback_splits;
+    return q;
+}
+
 extern "C" int lav_bert_layer_bwd(void* stream, void* side_stream, const lav_bert_layer_bwd_desc* b) {
     LAV_REQUIRE(b, "lav_bert_layer_bwd: null descriptor");
     const lav_bert_layer_desc* d = &b->f;
@@ -116,13 +126,14 @@ extern "C" int lav_bert_layer_bwd(void* stream, void* side_stream, const lav_ber
         LAV_TRY(lav_layernorm_bwd(stream, R, H, b->dy, H, d->pre2, H, nullptr, d->ln2_gamma, d->mean2, d->rstd2, nullptr, 0, b->d_pre2, H,
                                   b->g_ln2_gamma, b->g_ln2_beta, &ex));
     }
-    LAV_TRY(dw_gemm(ms, ss, H, F, R, b->d_dense2, d->h, b->g_w_ff2, b->splits_ff2, nullptr));
+    const bool grouped = b->group_splits > 0 && ss != ms;
+    if (!grouped) LAV_TRY(dw_gemm(ms, ss, H, F, R, b->d_dense2, d->h, b->g_w_ff2, b->splits_ff2, nullptr));
     {
         lav_gemm_epilogue e = epi0();
         e.gelu_in = d->h_pre; e.ldg = F; e.gelu_in_is_grad = 1; e.colsum = b->g_b_ff1;
         LAV_TRY(lav_gemm_bf16(stream, 0, R, F, H, b->d_dense2, H, b->wt_ff2, b->ldt_ff2, b->dh, F, &e, 1));
     }
-    LAV_TRY(dw_gemm(ms, ss, F, H, R, b->dh, d->x1, b->g_w_ff1, b->splits_ff1, nullptr));
+    if (!grouped) LAV_TRY(dw_gemm(ms, ss, F, H, R, b->dh, d->x1, b->g_w_ff1, b->splits_ff1, nullptr));
     {
         lav_gemm_epilogue e = epi0();
         e.residual = b->d_pre2; e.ldr = H;
@@ -135,7 +146,7 @@ extern "C" int lav_bert_layer_bwd(void* stream, void* side_stream, const lav_ber
         LAV_TRY(lav_layernorm_bwd(stream, R, H, b->d_x1, H, d->pre1, H, nullptr, d->ln1_gamma, d->mean1, d->rstd1, nullptr, 0, b->d_pre1, H,
                                   b->g_ln1_gamma, b->g_ln1_beta, &ex));
     }
-    LAV_TRY(dw_gemm(ms, ss, H, H, R, b->d_dense1, d->cx, b->g_w_ao, b->splits_ao, nullptr));
+    if (!grouped) LAV_TRY(dw_gemm(ms, ss, H, H, R, b->d_dense1, d->cx, b->g_w_ao, b->splits_ao, nullptr));
     {
         lav_gemm_epilogue e = epi0();
         LAV_TRY(lav_gemm_bf16(stream, 0, R, H, H, b->d_dense1, H, b->wt_ao, b->ldt_ao, b->d_cx, H, &e, 1));
@@ -145,7 +156,13 @@ extern "C" int lav_bert_layer_bwd(void* stream, void* side_stream, const lav_ber
         seq_desc(d, a);
         LAV_TRY(lav_attention_bwd(stream, &a, d->qkv, d->cx, b->d_cx, d->lse, b->dqkv, nullptr));
     }
-    LAV_TRY(dw_gemm(ms, ss, 3 * H, H, R, b->dqkv, d->x, b->g_w_qkv, b->splits_qkv, b->g_b_qkv));
+    if (grouped) {
+        // the layer's four weight gradients as ONE launch on the weight-gradient stream, now that the last operand (dqkv) exists
+        const lav_gemm_tn_job jobs[4] = {tn_job(H, F, R, b->d_dense2, d->h, b->g_w_ff2, b->splits_ff2, nullptr), tn_job(F, H, R, b->dh, d->x1, b->g_w_ff1, b->splits_ff1, nullptr),
+                                         tn_job(H, H, R, b->d_dense1, d->cx, b->g_w_ao, b->splits_ao, nullptr), tn_job(3 * H, H, R, b->dqkv, d->x, b->g_w_qkv, b->splits_qkv, b->g_b_qkv)};
+        LAV_TRY(fork_to(ms, ss));
+        LAV_TRY(lav_gemm_tn_grouped(ss, 4, jobs, b->group_splits));
+    } else LAV_TRY(dw_gemm(ms, ss, 3 * H, H, R, b->dqkv, d->x, b->g_w_qkv, b->splits_qkv, b->g_b_qkv));
     {
         lav_gemm_epilogue e = epi0();
         e.residual = b->d_pre1; e.ldr = H;
@@ -207,13 +224,14 @@ extern "C" int lav_swin_block_bwd(void* stream, void* side_stream, const lav_swi
     hipStream_t ms = (hipStream_t)stream, ss = side_stream ? (hipStream_t)side_stream : ms;
     const int M = d->rows, C = d->C, rpg = d->rows_per_group;
     // MLP branch: out = x_mid + s * fc2(gelu(fc1(LN2(x_mid))))
-    LAV_TRY(dw_gemm_keep(ms, ss, C, 4 * C, M, b->dy, d->h, b->g_w_fc2, b->splits_fc2, b->g_b_fc2, d->dp_mlp, rpg, b->alpha_mlp));
+    const bool grouped = b->group_splits > 0 && ss != ms;
+    if (!grouped) LAV_TRY(dw_gemm_keep(ms, ss, C, 4 * C, M, b->dy, d->h, b->g_w_fc2, b->splits_fc2, b->g_b_fc2, d->dp_mlp, rpg, b->alpha_mlp));
     {
         lav_gemm_epilogue e = epi0();
         e.gelu_in = d->h_pre; e.ldg = 4 * C; e.gelu_in_is_grad = 1; e.row_scale = d->dp_mlp; e.rows_per_group = rpg; e.colsum = b->g_b_fc1;
         LAV_TRY(lav_gemm_bf16(stream, 0, M, 4 * C, C, b->dy, C, b->wt_fc2, b->ldt_fc2, b->dh, 4 * C, &e, 1));
     }
-    LAV_TRY(dw_gemm(ms, ss, 4 * C, C, M, b->dh, d->y2, b->g_w_fc1, b->splits_fc1, nullptr));
+    if (!grouped) LAV_TRY(dw_gemm(ms, ss, 4 * C, C, M, b->dh, d->y2, b->g_w_fc1, b->splits_fc1, nullptr));
     {
         lav_gemm_epilogue e = epi0();
         LAV_TRY(lav_gemm_bf16(stream, 0, M, C, 4 * C, b->dh, 4 * C, b->wt_fc1, b->ldt_fc1, b->d_y2, C, &e, 1));
@@ -221,7 +239,7 @@ extern "C" int lav_swin_block_bwd(void* stream, void* side_stream, const lav_swi
     LAV_TRY(lav_layernorm_bwd(stream, M, C, b->d_y2, C, d->x_mid, C, nullptr, d->ln2_gamma, d->mean2, d->rstd2, b->dy, C, b->d_mid, C,
                               b->g_ln2_gamma, b->g_ln2_beta, nullptr));
     // attention branch: x_mid = x + s * proj(attn(qkv(LN1(x))))
-    LAV_TRY(dw_gemm_keep(ms, ss, C, C, M, b->d_mid, d->ao, b->g_w_proj, b->splits_proj, b->g_b_proj, d->dp_attn, rpg, b->alpha_attn));
+    if (!grouped) LAV_TRY(dw_gemm_keep(ms, ss, C, C, M, b->d_mid, d->ao, b->g_w_proj, b->splits_proj, b->g_b_proj, d->dp_attn, rpg, b->alpha_attn));
     {
         lav_gemm_epilogue e = epi0();
         e.row_scale = d->dp_attn; e.rows_per_group = rpg;
@@ -235,7 +253,14 @@ extern "C" int lav_swin_block_bwd(void* stream, void* side_stream, const lav_swi
     } else {
         LAV_TRY(lav_attention_bwd(stream, d->attn, d->qkv, d->ao, b->d_ao, d->lse, b->dqkv, b->g_bias_table));
     }
-    LAV_TRY(dw_gemm(ms, ss, 3 * C, C, M, b->dqkv, d->y1, b->g_w_qkv, b->splits_qkv, b->g_b_qkv));
+    if (grouped) {
+        const lav_gemm_tn_job jobs[4] = {tn_job(C, 4 * C, M, b->dy, d->h, b->g_w_fc2, b->splits_fc2, b->g_b_fc2, d->dp_mlp, rpg, b->alpha_mlp),
+                                         tn_job(4 * C, C, M, b->dh, d->y2, b->g_w_fc1, b->splits_fc1, nullptr),
+                                         tn_job(C, C, M, b->d_mid, d->ao, b->g_w_proj, b->splits_proj, b->g_b_proj, d->dp_attn, rpg, b->alpha_attn),
+                                         tn_job(3 * C, C, M, b->dqkv, d->y1, b->g_w_qkv, b->splits_qkv, b->g_b_qkv)};
+        LAV_TRY(fork_to(ms, ss));
+        LAV_TRY(lav_gemm_tn_grouped(ss, 4, jobs, b->group_splits));
+    } else LAV_TRY(dw_gemm(ms, ss, 3 * C, C, M, b->dqkv, d->y1, b->g_w_qkv, b->splits_qkv, b->g_b_qkv));
     {
         lav_gemm_epilogue e = epi0();
         LAV_TRY(lav_gemm_bf16(stream, 0, M, C, 3 * C, b->dqkv, 3 * C, b->wt_qkv, b->ldt_qkv, b->d_y1, C, &e, 1));

@@ -306,8 +306,9 @@ class SwinBlockFn(torch.autograd.Function):
         has_dp = ctx.has_dp
         splits = (K.splits_for(3 * Cn, Cn, M), K.splits_for(Cn, Cn, M, has_dp), K.splits_for(4 * Cn, Cn, M), K.splits_for(Cn, 4 * Cn, M, has_dp))
         b = ctx.c_consts["bwd"]
+        gs = K.group_splits_for(((Cn, 4 * Cn), (4 * Cn, Cn), (Cn, Cn), (3 * Cn, Cn)), M)
         fields = ctx.c_fields + (dy.data_ptr(), alpha, alpha) + b[:21] + splits + (
-            dh.data_ptr(), d_y2.data_ptr(), d_mid.data_ptr(), d_ao.data_ptr(), dqkv.data_ptr(), d_y1.data_ptr(), dx.data_ptr())
+            dh.data_ptr(), d_y2.data_ptr(), d_mid.data_ptr(), d_ao.data_ptr(), dqkv.data_ptr(), d_y1.data_ptr(), dx.data_ptr(), gs)
         side = dw_stream(dev) if _DW_SIDE else None
         K.swin_block_bwd(fields, side.cuda_stream if side is not None else None)
         if side is not None:
@@ -732,9 +733,10 @@ class BertLayerFn(torch.autograd.Function):
         dh, dqkv = e((R, F), dtype=bf16, device=dev), e((R, 3 * Hd), dtype=bf16, device=dev)
         splits = (K.splits_for(3 * Hd, Hd, R), K.splits_for(Hd, Hd, R), K.splits_for(F, Hd, R), K.splits_for(Hd, F, R))
         b = c["bwd"]
+        gs = K.group_splits_for(((Hd, F), (F, Hd), (Hd, Hd), (3 * Hd, Hd)), R)
         fields = ctx.c_fields + (dy.data_ptr(),) + b[:20] + splits + (
             d_pre2.data_ptr(), d_dense2.data_ptr(), dh.data_ptr(), d_x1.data_ptr(), d_pre1.data_ptr(), d_dense1.data_ptr(), d_cx.data_ptr(),
-            dqkv.data_ptr(), dx.data_ptr())
+            dqkv.data_ptr(), dx.data_ptr(), gs)
         side = dw_stream(dev) if _DW_SIDE else None
         K.bert_layer_bwd(fields, side.cuda_stream if side is not None else None)
         if side is not None:                                   # operands of the weight-gradient GEMMs: not to be recycled before the side stream ran

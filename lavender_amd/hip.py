@@ -105,9 +105,24 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
     return out[:, :N] if out.shape[-1] != N else out
 
 
+def gemm_tn_grouped(jobs, splits):
+    """Grouped weight gradients (lav_gemm_tn_grouped): jobs = up to four dicts with A [K, M], B [K, N] (bf16), out [M, N] (fp32, accumulated)
+    and optionally rowsum_a, k_keep, k_rows_per_group, alpha, fallback_splits; one launch when every job fits the 256 x 256 weight-gradient kernel."""
+    arr = (L.GemmTnJob * len(jobs))()
+    for q, j in zip(arr, jobs):
+        A, B, out = j["A"], j["B"], j["out"]
+        q.K, q.M, q.N = A.shape[0], j.get("M", A.shape[1]), j.get("N", B.shape[1])
+        q.A, q.lda, q.B, q.ldb, q.C, q.ldc = A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), out.data_ptr(), _ld(out)
+        q.rowsum_a, q.k_keep = _dp(j.get("rowsum_a")), _dp(j.get("k_keep"))
+        q.k_rows_per_group, q.alpha, q.fallback_splits = int(j.get("k_rows_per_group", 1)), float(j.get("alpha", 1.0)), int(j.get("fallback_splits", 1))
+    rc = L.lib.lav_gemm_tn_grouped(_s(), len(jobs), arr, int(splits))
+    if rc != 0:
+        L.check(rc, "lav_gemm_tn_grouped")
+
+
 # ---- stage-level entries (lavender_amd/csrc/stages.cpp): one C call per fusion-encoder layer pass ------------------------------------
 _BL_FWD_PACK = _struct.Struct("@5i3f3Ii32Pi4x")
-_BL_BWD_PACK = _struct.Struct("@5i3f3Ii32Pi5P4q12P4i9P")
+_BL_BWD_PACK = _struct.Struct("@5i3f3Ii32Pi5P4q12P4i9Pi4x")
 assert _BL_FWD_PACK.size == C.sizeof(L.BertLayerDesc) and _BL_BWD_PACK.size == C.sizeof(L.BertLayerBwdDesc)
 
 
@@ -120,7 +135,7 @@ def _stage_buffers():
 
 
 _SB_FWD_PACK = _struct.Struct("@5if29P")
-_SB_BWD_PACK = _struct.Struct("@5if29PP2f4P4q13P4i7P")
+_SB_BWD_PACK = _struct.Struct("@5if29PP2f4P4q13P4i7Pi4x")
 assert _SB_FWD_PACK.size == C.sizeof(L.SwinBlockDesc) and _SB_BWD_PACK.size == C.sizeof(L.SwinBlockBwdDesc)
 
 
@@ -186,6 +201,24 @@ def splits_for(M, N, K, keep=False):
         return 1
     s = 5 if tiles > 128 else max(1, 256 // tiles)
     return int(max(1, min(s, 256, (K + 255) // 256)))
+
+
+_TN_GROUP = _os.environ.get("LAV_GEMM_TN_GROUP", "1") != "0"
+_TN_GROUP_BLOCKS = int(_os.environ.get("LAV_TN_GROUP_BLOCKS", "192"))      # target workgroups of a grouped weight-gradient launch (sweep: profiles/r04_late_experiments.md section 11)
+_TN_GROUP_BLOCKS_WIDE = int(_os.environ.get("LAV_TN_GROUP_BLOCKS_WIDE", str(_TN_GROUP_BLOCKS)))   # probe hook: the same for groups of >= 96 tiles (the fusion layers)
+
+
+def group_splits_for(shapes, K):
+    """split factor of a GROUPED weight-gradient launch over the (M, N) outputs `shapes` with contraction K (lav_gemm_tn_grouped), 0 when the
+    group does not apply (an output the 256 x 256 kernel cannot take: the stage entries then launch one by one with splits_for)."""
+    if not _TN_GROUP or K % 32:
+        return 0
+    tiles = 0
+    for M, N in shapes:
+        if N % 256 or M < (_TN_MINM if N >= 512 else max(_TN_MINM, 256)):
+            return 0
+        tiles += ((M + 255) // 256) * (N // 256)
+    return int(max(1, min(round((_TN_GROUP_BLOCKS_WIDE if tiles >= 96 else _TN_GROUP_BLOCKS) / tiles), K // 256)))
 
 
 def splits_nn(M, N, K):

@@ -343,6 +343,45 @@ def test_gemm_ragged_vocab_with_writable_padding():
     assert torch.equal(ref[:, :V], buf[:, :V]) and (ref[:, V:] == 7.0).all()
 
 
+@pytest.mark.parametrize("shapes,Kd,splits,rpg", [
+    ([(512, 2048), (2048, 512), (1536, 512), (512, 512)], 31360 // 4, 3, 980),       # a Swin-B stage-2 block (a quarter of the batch), drop-path masks
+    ([(768, 3072), (3072, 768), (2304, 768), (768, 768)], 2 * 282 * 8, 1, 0),         # a fusion layer, no split at all
+    ([(1024, 4096), (4096, 1024)], 7840, 2, 245),                                     # stage 3: contraction a multiple of 32, not of 64
+    ([(512, 512), (96, 512)], 4096, 2, 0),                                            # a job the large kernel cannot take: everything falls back
+])
+def test_grouped_weight_gradient_gemm_matches_the_separate_launches(shapes, Kd, splits, rpg):
+    """lav_gemm_tn_grouped: up to four C_j += alpha_j A_j^T B_j in one launch of the weight-gradient kernel (bias row sums and stochastic-depth
+    row skipping included) against the same products launched one by one: equal up to fp32 summation order (different split factors), and
+    ACCUMULATED onto what C held."""
+    g = torch.Generator().manual_seed(17)
+    jobs, refs = [], []
+    for i, (M, N) in enumerate(shapes):
+        A, B = rb(Kd, M, scale=0.5, seed=i), rb(Kd, N, scale=0.5, seed=50 + i)
+        base = torch.randn(M, N, generator=g).cuda()
+        keep = None
+        if rpg and i % 2 == 0:
+            ns = -(-Kd // rpg)
+            keep = (torch.rand(ns, generator=g) > 0.3).float().cuda()
+        want_rs = i % 2 == 1
+        alpha = 1.25 if keep is not None else 1.0
+        o_ref, o_grp = base.clone(), base.clone()
+        rs_ref = torch.zeros(M, device="cuda") if want_rs else None
+        rs_grp = torch.zeros(M, device="cuda") if want_rs else None
+        K().gemm(2, A, B, M, N, Kd, out=o_ref, accumulate=True, splits=K().splits_for(M, N, Kd, keep is not None), rowsum_a=rs_ref, k_keep=keep,
+                 k_rows_per_group=rpg or 1, alpha=alpha)
+        jobs.append(dict(A=A, B=B, out=o_grp, rowsum_a=rs_grp, k_keep=keep, k_rows_per_group=rpg or 1, alpha=alpha,
+                         fallback_splits=K().splits_for(M, N, Kd, keep is not None)))
+        refs.append((o_ref, rs_ref, base))
+    K().gemm_tn_grouped(jobs, splits)
+    torch.cuda.synchronize()
+    for j, (o_ref, rs_ref, base) in zip(jobs, refs):
+        scale = (o_ref - base).abs().max().item()
+        assert scale > 0
+        close(j["out"], o_ref, atol=2e-5 * scale + 1e-5, rtol=1e-5, what="grouped weight gradient")
+        if rs_ref is not None:
+            close(j["rowsum_a"], rs_ref, atol=1e-3 * rs_ref.abs().max().item() + 1e-4, rtol=1e-4, what="grouped bias row sums")
+
+
 def test_fp16_rows_of_the_residual_stream_gemm_and_layernorm():
     """The fusion encoder's wide residual stream as fp16 rows (lav_gemm_epilogue.out_mode 3 / residual_f32 2, lav_ln_f32.x_f32 2,
     lav_ln_bwd_extra.x_f32 2).  With values that are exactly representable as halves, every kernel must give the SAME bits as with the fp32

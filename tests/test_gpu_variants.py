@@ -543,8 +543,9 @@ def test_stage_level_c_entries_match_the_per_kernel_path(size):
         torch.cuda.synchronize()
         return logits, {n: ar.params[n].grad.clone() for n in wnames}, ar.grad.clone()
 
-    keep = E.STAGE_C
+    keep, keep_group = E.STAGE_C, K._TN_GROUP
     try:
+        K._TN_GROUP = False                                      # one weight-gradient launch per nn.Linear, as the per-kernel path issues them
         ref_logits, ref, ref_all = run(False)
         for rep in range(3):
             logits, got, got_all = run(True)
@@ -552,5 +553,14 @@ def test_stage_level_c_entries_match_the_per_kernel_path(size):
             bad = [n for n in wnames if not torch.equal(got[n], ref[n])]
             assert not bad, (rep, bad[:5])
             assert ((got_all - ref_all).norm() / ref_all.norm()).item() < 1e-5
+        # the shipped form: a stage's four weight gradients as ONE grouped launch (lav_gemm_tn_grouped) -- other split factors, so the fp32
+        # sums differ in their last bits; everything else is unchanged
+        K._TN_GROUP = True
+        logits, got, got_all = run(True)
+        assert torch.equal(logits[0], ref_logits[0]) and torch.equal(logits[1], ref_logits[1])
+        for n in wnames:
+            d = (got[n] - ref[n]).norm().item()
+            assert d <= 2e-5 * ref[n].norm().item() + 1e-12, (n, d, ref[n].norm().item())
+        assert ((got_all - ref_all).norm() / ref_all.norm()).item() < 1e-5
     finally:
-        E.STAGE_C = keep
+        E.STAGE_C, K._TN_GROUP = keep, keep_group
