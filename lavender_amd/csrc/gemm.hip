@@ -1389,12 +1389,12 @@ __global__ __launch_bounds__(512) void gemm_pp_group_kernel(GemmGroup G) {
 // ---- split-K reduction: C[r][c] += sum_s ws[s][tile(r,c)][r % 128][c % 128] -------------------------------------
 // 64 float4 outputs per block x 4 split lanes (each sums every 4th split, loads unrolled for memory parallelism),
 // merged through LDS; one plain read-modify-write of C per output.
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, int tiles, int tiles_n, int rpt, int M,
-                                                       int N, float* __restrict__ C, long ldc) {
+__device__ __forceinline__ void tn_reduce_body(const float* __restrict__ ws, int splits, int tiles, int tiles_n, int rpt, int M,
+                                               int N, float* __restrict__ C, long ldc, int block) {
     __shared__ float4 part[4][64];
     const int n4 = N >> 2;
     const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long idx = (long)blockIdx.x * 64 + o;
+    const long idx = (long)block * 64 + o;
     const bool valid = idx < (long)M * n4;
     const int row = valid ? (int)(idx / n4) : 0, col = valid ? (int)(idx % n4) * 4 : 0;
     const long off = ((long)(row / rpt) * tiles_n + col / BN) * (rpt * BN) + (row % rpt) * BN + (col % BN);   // rpt rows per tile
@@ -1425,6 +1425,24 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
         r.z += (a.z + b.z) + (c.z + d.z); r.w += (a.w + b.w) + (c.w + d.w);
         *p = r;
     }
+}
+
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int splits, int tiles, int tiles_n, int rpt, int M,
+                                                       int N, float* __restrict__ C, long ldc) {
+    tn_reduce_body(ws, splits, tiles, tiles_n, rpt, M, N, C, ldc, (int)blockIdx.x);
+}
+// the reductions of a grouped weight-gradient launch (lav_gemm_tn_grouped) as one launch
+struct TnReduceJob { const float* ws; float* C; long ldc; int splits, tiles, tiles_n, rpt, M, N, blk0, pad_; };
+struct TnReduceGroup { int n; TnReduceJob j[4]; };
+__global__ __launch_bounds__(256) void tn_reduce_group_kernel(TnReduceGroup G) {
+    const int b = (int)blockIdx.x;
+    int p = 0;
+    if (G.n > 3 && b >= G.j[3].blk0) p = 3; else if (G.n > 2 && b >= G.j[2].blk0) p = 2; else if (G.n > 1 && b >= G.j[1].blk0) p = 1;
+    // constant indices: the job is read from the kernel arguments (no scratch copy of the table)
+    if (p == 3) tn_reduce_body(G.j[3].ws, G.j[3].splits, G.j[3].tiles, G.j[3].tiles_n, G.j[3].rpt, G.j[3].M, G.j[3].N, G.j[3].C, G.j[3].ldc, b - G.j[3].blk0);
+    else if (p == 2) tn_reduce_body(G.j[2].ws, G.j[2].splits, G.j[2].tiles, G.j[2].tiles_n, G.j[2].rpt, G.j[2].M, G.j[2].N, G.j[2].C, G.j[2].ldc, b - G.j[2].blk0);
+    else if (p == 1) tn_reduce_body(G.j[1].ws, G.j[1].splits, G.j[1].tiles, G.j[1].tiles_n, G.j[1].rpt, G.j[1].M, G.j[1].N, G.j[1].C, G.j[1].ldc, b - G.j[1].blk0);
+    else tn_reduce_body(G.j[0].ws, G.j[0].splits, G.j[0].tiles, G.j[0].tiles_n, G.j[0].rpt, G.j[0].M, G.j[0].N, G.j[0].C, G.j[0].ldc, b);
 }
 
 // split-K of a forward / input-gradient GEMM (bf16 output, no epilogue): C = bf16(sum_s ws[s]); 8 columns per thread
@@ -1776,13 +1794,18 @@ extern "C" int lav_gemm_tn_grouped(void* stream, int n_jobs, const lav_gemm_tn_j
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)gemm_pp_group_kernel<true, EF_TNFLUSH>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS); (void)hipGetLastError(); attr = true; }
     hipLaunchKernelGGL((gemm_pp_group_kernel<true, EF_TNFLUSH>), dim3(blocks), dim3(512), PP_LDS, s, G);
+    TnReduceGroup R;
+    memset(&R, 0, sizeof(R));
+    int rblocks = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const GemmArgs& g = G.g[j];
         if (g.splits > 1) {
-            const long n = (long)g.M * (g.N / 4);
-            hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, g.ws, g.splits, ws_tiles[j], (g.N + BN - 1) / BN, BIG_BM, g.M, g.N,
-                               (float*)g.C, g.ldc);
+            TnReduceJob& q = R.j[R.n++];
+            q.ws = g.ws; q.C = (float*)g.C; q.ldc = g.ldc; q.splits = g.splits; q.tiles = ws_tiles[j]; q.tiles_n = (g.N + BN - 1) / BN; q.rpt = BIG_BM; q.M = g.M; q.N = g.N;
+            q.blk0 = rblocks;
+            rblocks += (int)(((long)g.M * (g.N / 4) + 63) / 64);
         }
     }
+    if (R.n) hipLaunchKernelGGL(tn_reduce_group_kernel, dim3(rblocks), dim3(256), 0, s, R);
     return lav_check_launch("lav_gemm_tn_grouped");
 }
