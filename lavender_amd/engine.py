@@ -95,6 +95,33 @@ def dw_gemm(A, Bm, M, N, Kd, **kw):
             t.record_stream(side)
 
 
+class DwGroup:
+    """The weight-gradient GEMMs of one stage collected and issued as ONE grouped launch on the weight-gradient stream (lav_gemm_tn_grouped;
+    the stage-level C entries do the same from C).  add() has dw_gemm's meaning; launch() after the last operand was produced.  Without the
+    side stream or with LAV_GEMM_TN_GROUP=0 every add() launches at once, as dw_gemm does."""
+
+    def __init__(self, shapes, Kd):
+        self.gs = K.group_splits_for(shapes, Kd) if _DW_SIDE else 0
+        self.jobs = []
+
+    def add(self, A, Bm, M, N, Kd, out, splits, rowsum_a=None):
+        if not self.gs:
+            return dw_gemm(A, Bm, M, N, Kd, out=out, accumulate=True, splits=splits, rowsum_a=rowsum_a)
+        self.jobs.append(dict(A=A, B=Bm, M=M, N=N, out=out, rowsum_a=rowsum_a, fallback_splits=splits))
+
+    def launch(self, device):
+        if not self.jobs:
+            return
+        side = dw_stream(device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            K.gemm_tn_grouped(self.jobs, self.gs)
+        for j in self.jobs:
+            j["A"].record_stream(side)
+            j["B"].record_stream(side)
+        self.jobs = []
+
+
 _LN_SIDE = os.environ.get("LAV_LN_FINISH_SIDE", "0") != "0"     # measured neutral on the cfg2 step (76.3 vs 76.3-76.6 ms): off by default
 
 
@@ -763,16 +790,17 @@ class BertLayerFn(torch.autograd.Function):
         d_dense2 = torch.empty((R, Hd), dtype=bf16, device=x.device)
         d_pre2 = ln_bwd(dy, pre2, R, Hd, outp.LayerNorm.weight.data, mean2, rstd2, G(outp.LayerNorm.weight),
                                  G(outp.LayerNorm.bias), dx2=d_dense2, dropout_p=p, seed=s2, colsum=G(outp.dense.bias))
-        dw_gemm(d_dense2, h, Hd, F, R, out=G(outp.dense.weight), accumulate=True, splits=K.splits_for(Hd, F, R))
+        grp = DwGroup(((Hd, F), (F, Hd), (Hd, Hd), (3 * Hd, Hd)), R)      # the layer's four weight gradients: one grouped launch at the end
+        grp.add(d_dense2, h, Hd, F, R, G(outp.dense.weight), K.splits_for(Hd, F, R))
         dh = K.gemm(0, d_dense2, W16T(outp.dense.weight), R, F, Hd, gelu_in=h_pre, gelu_in_is_grad=_GQ, colsum=G(inter.dense.bias))
-        dw_gemm(dh, x1, F, Hd, R, out=G(inter.dense.weight), accumulate=True, splits=K.splits_for(F, Hd, R))
+        grp.add(dh, x1, F, Hd, R, G(inter.dense.weight), K.splits_for(F, Hd, R))
         d_x1 = K.gemm(0, dh, W16T(inter.dense.weight), R, Hd, F, residual=d_pre2)
         del dh
         # x1 = LN(pre1), pre1 = x + dropout(dense(ctx))
         d_dense1 = torch.empty_like(d_dense2) if _DW_SIDE else d_dense2     # the side stream may still read d_dense2
         d_pre1 = ln_bwd(d_x1, pre1, R, Hd, ao.LayerNorm.weight.data, mean1, rstd1, G(ao.LayerNorm.weight),
                                  G(ao.LayerNorm.bias), dx2=d_dense1, dropout_p=p, seed=s1, colsum=G(ao.dense.bias))
-        dw_gemm(d_dense1, cx, Hd, Hd, R, out=G(ao.dense.weight), accumulate=True, splits=K.splits_for(Hd, Hd, R))
+        grp.add(d_dense1, cx, Hd, Hd, R, G(ao.dense.weight), K.splits_for(Hd, Hd, R))
         d_cx = K.gemm(0, d_dense1, W16T(ao.dense.weight), R, Hd, Hd)
         dqkv = torch.empty_like(qkv)
         att.bwd(qkv, cx, d_cx, lse, dqkv, None)
@@ -783,10 +811,12 @@ class BertLayerFn(torch.autograd.Function):
             U = x.shape[0]
             dqkv_u = K.gather_sum_rows(dqkv, start, order, U, 3 * Hd)
             d_pre1_u = K.gather_sum_rows(d_pre1, start, order, U, Hd)
-            dw_gemm(dqkv_u, x, 3 * Hd, Hd, U, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, U), rowsum_a=gbqkv)
+            grp.add(dqkv_u, x, 3 * Hd, Hd, U, gwqkv, K.splits_for(3 * Hd, Hd, U), rowsum_a=gbqkv)
+            grp.launch(x.device)
             dx = K.gemm(0, dqkv_u, W16T(att_m.query.weight), U, Hd, 3 * Hd, residual=d_pre1_u)
             return None, dx, None, None, None, None, None, None, None, None, None, None
-        dw_gemm(dqkv, x, 3 * Hd, Hd, R, out=gwqkv, accumulate=True, splits=K.splits_for(3 * Hd, Hd, R), rowsum_a=gbqkv)
+        grp.add(dqkv, x, 3 * Hd, Hd, R, gwqkv, K.splits_for(3 * Hd, Hd, R), rowsum_a=gbqkv)
+        grp.launch(x.device)
         dx = K.gemm(0, dqkv, W16T(att_m.query.weight), R, Hd, 3 * Hd, residual=d_pre1)
         return None, dx, None, None, None, None, None, None, None, None, None, None
 
