@@ -1134,8 +1134,11 @@ __device__ __forceinline__ void pp_wait_tiles(int rem) {   // s_waitcnt vmcnt(4 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// walk: 0 = per-job XCD runs, n-fastest tiles (rounds 2-4); 1 = the caller has already placed `bid_in` (grouped launch: XCD runs over the
+// WHOLE launch, so an XCD's ~27 co-resident blocks are consecutive tiles of ONE job and ONE K-slab) and the tiles of a slab are walked
+// short-dimension-fastest: a run of L tiles then touches short + L / short operand panels instead of up to 2 L / long + long.
 template <bool TN, unsigned F, int DBG = 0>
-__device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int bid_in) {
+__device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int bid_in, int walk = 0) {
     static_assert(TN && F == EF_TNFLUSH && DBG == 0, "ping-pong kernel: weight-gradient layout only (the K-contiguous form was removed in round 4)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1144,14 +1147,15 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int bid_in) {
     const int tiles_n = (g.N + 255) / 256, tiles_m = (g.M + BIG_BM - 1) / BIG_BM;
     const int nwg = tiles_m * tiles_n;
     int bid = bid_in;
-    {
+    if (!(walk & 1)) {
         const int tot = nwg * g.splits;
         int q = tot >> 3, r = tot & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int split = bid / nwg;
     bid -= split * nwg;
-    const int m0 = (bid / tiles_n) * BIG_BM, n0 = (bid % tiles_n) * 256;
+    const bool m_fast = (walk & 2) && tiles_m < tiles_n;
+    const int m0 = (m_fast ? bid % tiles_m : bid / tiles_n) * BIG_BM, n0 = (m_fast ? bid / tiles_m : bid % tiles_n) * 256;
     const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nk = (kend - kbeg) / PP_BK;
@@ -1376,14 +1380,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) { gemm_pp_body
 // parts.  Block b belongs to the job whose first block is the largest blk0 <= b; the job is selected by an if-chain over CONSTANT
 // indices so that every copy of the body reads its GemmArgs straight from the kernel arguments (a run-time index would make the compiler
 // copy the 1.6 KB table to scratch).
-struct GemmGroup { int n; int blk0[4]; GemmArgs g[4]; };
+struct GemmGroup { int n; int walk; int blk0[4]; GemmArgs g[4]; };
 template <bool TN, unsigned F>
 __global__ __launch_bounds__(512) void gemm_pp_group_kernel(GemmGroup G) {
-    const int b = (int)blockIdx.x;
-    if (G.n > 3 && b >= G.blk0[3]) gemm_pp_body<TN, F>(G.g[3], b - G.blk0[3]);
-    else if (G.n > 2 && b >= G.blk0[2]) gemm_pp_body<TN, F>(G.g[2], b - G.blk0[2]);
-    else if (G.n > 1 && b >= G.blk0[1]) gemm_pp_body<TN, F>(G.g[1], b - G.blk0[1]);
-    else gemm_pp_body<TN, F>(G.g[0], b);
+    int b = (int)blockIdx.x;
+    if (G.walk & 1) {
+        // hardware block b runs on XCD b % 8: give each XCD one contiguous run of the launch's (job, K-slab, tile) sequence
+        const int tot = (int)gridDim.x;
+        const int q = tot >> 3, r = tot & 7, xcd = b & 7, idx = b >> 3;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    if (G.n > 3 && b >= G.blk0[3]) gemm_pp_body<TN, F>(G.g[3], b - G.blk0[3], G.walk);
+    else if (G.n > 2 && b >= G.blk0[2]) gemm_pp_body<TN, F>(G.g[2], b - G.blk0[2], G.walk);
+    else if (G.n > 1 && b >= G.blk0[1]) gemm_pp_body<TN, F>(G.g[1], b - G.blk0[1], G.walk);
+    else gemm_pp_body<TN, F>(G.g[0], b, G.walk);
 }
 
 // ---- split-K reduction: C[r][c] += sum_s ws[s][tile(r,c)][r % 128][c % 128] -------------------------------------
@@ -1765,6 +1775,8 @@ extern "C" int lav_gemm_tn_grouped(void* stream, int n_jobs, const lav_gemm_tn_j
     GemmGroup G;
     memset(&G, 0, sizeof(G));
     G.n = n_jobs;
+    static const int tn_walk = getenv("LAV_TN_WALK") ? atoi(getenv("LAV_TN_WALK")) : 3;   // probe hook for the A/B of profiles/r05_dw_walk.md: 0 = the round-4 walk
+    G.walk = tn_walk;
     size_t ws_off[4] = {0, 0, 0, 0}, ws_bytes = 0;
     int ws_tiles[4] = {0, 0, 0, 0}, blocks = 0;
     for (int j = 0; j < n_jobs; ++j) {
