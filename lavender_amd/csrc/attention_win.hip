@@ -68,6 +68,15 @@ __device__ __forceinline__ bf16x8 tr_frag_k32(const char* tile, int key0, int la
     return u.v;
 }
 
+// the same fragment from two ready addresses (the two ds_read_b64_tr_b16 of a tr_frag_k32)
+__device__ __forceinline__ bf16x8 tr_pair(const char* p_lo, const char* p_hi) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p_lo);
+    s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p_hi);
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi4;
+    return u.v;
+}
+
 // byte offset (relative to the sample's first token row) of lane `lane`'s 16 bytes of DMA piece t of a [256 rows][64 B] K-type
 // image: piece t covers window rows 16 t .. 16 t + 15; the lane lands on physical slot lane & 3 of row 16 t + (lane >> 2), so
 // it fetches the logical slot that the swizzle stores there.  ld = row stride in elements, col0 = first column of the head.
@@ -255,6 +264,9 @@ __global__ __launch_bounds__(512) void win_fwd3(AttnArgs a, int bsplit) {
                 *(uint2*)(op + 8 * r4 + 4 * hi) = w;
             }
             if (a.lse && hi == 0) a.lse[((long)(b * a.nWs + g.ws) * a.d.heads + g.head) * a.Npad + q] = m_run + log2f(l_tot);
+        } else if (a.lse && hi == 0 && q < a.Npad) {
+            // padded query slot of the last tile: lse = +inf makes every later exp2(s - lse) an exact 0 (win_bwd1 relies on it)
+            a.lse[((long)(b * a.nWs + g.ws) * a.d.heads + g.head) * a.Npad + q] = INFINITY;
         }
         dma_wait_all();
         __syncthreads();
@@ -538,6 +550,261 @@ __global__ __launch_bounds__(512) void win_dkv3(AttnArgs a, int bsplit, const fl
                     dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf.b, dv, 0, 0, 0);
                     bf16x8 qt_ = tr_frag_k32(Qs, q0 + 16 * sl, lane);
                     dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, df.b, dk, 0, 0, 0);
+                }
+            }
+            if (k_ok) {
+                bf16_t* op = a.dqkv + ((long)b * a.tps + krel) * ld + g.head * HD;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = 8 * r4 + 4 * hi;
+                    uint2 w;
+                    w.x = pack2(dk[r4 * 4 + 0] * a.d.scale, dk[r4 * 4 + 1] * a.d.scale);
+                    w.y = pack2(dk[r4 * 4 + 2] * a.d.scale, dk[r4 * 4 + 3] * a.d.scale);
+                    *(uint2*)(op + C + d) = w;
+                    w.x = pack2(dv[r4 * 4 + 0], dv[r4 * 4 + 1]);
+                    w.y = pack2(dv[r4 * 4 + 2], dv[r4 * 4 + 3]);
+                    *(uint2*)(op + 2 * C + d) = w;
+                }
+            }
+        }
+        dma_wait_all();
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, ONE pass (round 5): dQ, dK, dV of a (window, head) from a single evaluation of S and dP.
+//
+// Wave w owns key tile w: dK / dV accumulate in its registers over the query tiles (contraction over queries: P and dS are B
+// operands as they come out of the score MFMAs -- lane = key, registers = queries).  dQ contracts over KEYS, i.e. needs dS with
+// lane = query: the wave writes its bf16 dS tile to LDS as [key][query] rows and reads it back with the transposing
+// ds_read_b64_tr_b16 (the same fragment read the K^T operand uses), multiplies by its OWN 32 keys (K^T fragments resident in
+// registers) and adds the product to the query tile's fp32 accumulator, which lives in LDS and is handed from wave to wave:
+// at step s wave w works on query tile (w + s) mod NT, so the NT active waves always hold NT different tiles; the tile's
+// accumulator is read as the C operand of the dQ MFMAs and written back (first touch starts from zero, the last toucher packs
+// it to bf16 and stores dQ) -- no atomics, one workgroup barrier per step.  While a wave holds a tile's accumulator in registers
+// that tile's LDS slot is dead, so its first 2 KB serve as the wave's dS^T scratch.
+// delta[q] = dO[q] . O[q] is computed at the top of a sample by the wave whose index is the query strip (O arrives as a
+// wave-private strip) and shared through LDS; -delta also goes to global memory for win_dbias3 (weight-gradient stream).
+// What two passes cost: S, dP, the exponentials and both packs twice (18 MFMAs + 2 x 16 exp per tile pair, now 12 + 16), q / k / v / dO
+// fetched twice, lse / delta round trips.  Padded query slots need no select: the forward stores lse = +inf for them.
+// LDS: [2][Q 16 KB | dO 16 KB | lse 1 KB] + -delta 1 KB + strips [8][K 2 KB | V 2 KB | O 2 KB] + dQ tiles [8][4 KB] + token rows 1 KB
+//      = 148 KB.
+// ------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* ndelta_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WinGeo g;
+    if (!win_geo(a, bsplit, blockIdx.x, g)) return;
+    constexpr int BUF = 16384 * 2 + 1024;
+    constexpr int ND_OFF = 2 * BUF, STRIP_OFF = ND_OFF + 1024, DQ_OFF = STRIP_OFF + 8 * 6144, SREL_OFF = DQ_OFF + 8 * 4096, FLAG_OFF = SREL_OFF + 1024;
+    static_assert((DQ_OFF & 0x30) == 0, "the dS^T scratch rows are addressed as (slot + lane part) ^ (chunk << 4)");
+    float* nd_l = (float*)(smem + ND_OFF);                    // -delta of the current sample
+    char* strips = smem + STRIP_OFF;
+    int* srel_l = (int*)(smem + SREL_OFF);                    // raw token rows (-1 = padded slot)
+    int* flags = (int*)(smem + FLAG_OFF);                     // flags[t] = contributions added to dQ tile t so far
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C, ld = 3 * C;
+    const float sc = a.d.scale * LOG2E, inv_sc = 1.0f / sc;
+    if (tid < 256) srel_l[tid] = a.d.tok_table[g.ws * 256 + tid];
+    const int key = wave * 32 + j;
+    const int krel = a.d.tok_table[g.ws * 256 + key];
+    const bool k_ok = krel >= 0;
+    const bool wave_on = wave < NT;                           // wave-uniform
+    // (bias + mask) / scale tiles of key tile `wave`, in the order this wave visits the query tiles: cb[s] = tile (wave + s) mod NT
+    const bf16_t* combT = (const bf16_t*)a.d.combT + ((long)(g.type * a.d.heads + g.head) * 64 + wave * 8) * 1024 + lane * 8;
+    Frag cb[NT][2];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        const int qt = wave_on ? (wave + s) % NT : 0;
+        cb[s][0].u = *(const uint4*)(combT + qt * 1024); cb[s][1].u = *(const uint4*)(combT + qt * 1024 + 512);
+    }
+    const bf16x8 id0 = ident_frag(0, j, hi), id1 = ident_frag(1, j, hi);
+    // Lane parts of the per-step LDS addresses.  The query tile of a step is a run-time (wave-uniform) value, so every address is
+    // (lane part) + (scalar tile offset) + immediate: tile offsets are multiples of 32 rows, which leaves the slot swizzles alone.
+    const int ko0 = krow_off<HD>(j, hi), ko1 = krow_off<HD>(j, 2 + hi);     // fragment rows j of a K-type image (Q / dO tiles)
+    int tr_lo, tr_hi;                                         // transposing fragment reads (tr_frag_k32 at a key0 that is a multiple of 16)
+    {
+        const int i = lane & 15, dhalf = (lane >> 4) & 1, r = i >> 2, c = i & 3;
+        const int dcol = 16 * dhalf + 4 * c, slot = dcol >> 3, sub = (dcol & 7) * 2;
+        tr_lo = (4 * hi + r) * 64 + ((slot ^ hi) << 4) + sub;
+        tr_hi = (4 * hi + r + 8) * 64 + ((slot ^ ((hi + 2) & 3)) << 4) + sub;
+    }
+    const int sw0 = j * 64 + 8 * hi + (((j >> 2) & 3) << 4);  // dS^T scratch row j, 16-byte chunk c at (slot + sw0) ^ (c << 4)
+    __syncthreads();
+    unsigned offq[2], offg[2], offk[2];
+    const QkvAddr qa = qkv_addr(a, g.head);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rel = max(srel_l[(wave * 2 + i) * 16 + (lane >> 2)], 0);
+        const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
+        offq[i] = (unsigned)(((long)rel * qa.rs + qa.col0 + lslot * 8) * 2);
+        offg[i] = (unsigned)((rel * C + g.head * HD + lslot * 8) * 2);
+        offk[i] = offq[i] + qa.pl_b;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned strip0 = lds0 + STRIP_OFF + wave * 6144;
+    const long lse_row = (long)g.ws * a.d.heads + g.head;
+    auto issue = [&](int b, int buf) {
+        const bf16_t* bq = a.qkv + (long)b * a.tps * qa.rs;
+        const bf16_t* bg = a.dout + (long)b * a.tps * C;
+        const bf16_t* bo = a.out + (long)b * a.tps * C;
+        const unsigned d0 = lds0 + buf * BUF + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dma16(d0 + i * 1024, bq, offq[i]);
+            dma16(d0 + 16384 + i * 1024, bg, offg[i]);
+            dma16(strip0 + i * 1024, bq, offk[i]);
+            dma16(strip0 + 2048 + i * 1024, bq, offk[i] + qa.pl_b);
+            dma16(strip0 + 4096 + i * 1024, bo, offg[i]);
+        }
+        if (wave == 0)
+            dma16(lds0 + buf * BUF + 32768, a.lse + ((long)b * a.nWs * a.d.heads + lse_row) * a.Npad, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
+    };
+    issue(g.b0, 0);
+    dma_wait_all();
+    __syncthreads();
+
+    for (int b = g.b0; b < g.b1; ++b) {
+        const int cur = (b - g.b0) & 1;
+        const char* Qs = smem + cur * BUF;
+        const char* Gs = Qs + 16384;
+        const char* Sk = strips + wave * 6144;
+        bf16x8 kf[2], vf[2], ktf[2];
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = ks ? ko1 : ko0;
+            kf[ks] = *(const bf16x8*)(Sk + off); vf[ks] = *(const bf16x8*)(Sk + 2048 + off);
+            ktf[ks] = tr_frag_k32(Sk, 16 * ks, lane);
+            Frag fo, fg;
+            fo.u = *(const uint4*)(Sk + 4096 + off);
+            fg.u = *(const uint4*)(Gs + wave * 2048 + off);
+            float gf[8], of[8];
+            unpack8(fg.u, gf); unpack8(fo.u, of);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl = fmaf(gf[e], of[e], dl);
+        }
+        dl = xhalf_sum(dl);
+        if (hi == 0) {
+            nd_l[key] = -dl;                                  // (key == this wave's query strip index here)
+            if (k_ok) ndelta_out[((long)b * a.nWs * a.d.heads + lse_row) * a.Npad + key] = -dl;
+        }
+        // the sample's lse row becomes -lse / (scale log2 e): it enters the score tiles as the C operand of their first MFMA, so the
+        // exponent argument is one multiply (and no register holds lse during the soft-max); +inf (padded query) stays -inf
+        if (tid < 256) { float* ll = (float*)(Qs + 32768); ll[tid] = -ll[tid] * inv_sc; }
+        if (tid < 8) flags[tid] = 0;
+        lds_wait_all();                                       // the strips are in registers: their LDS image may be overwritten
+        if (b + 1 < g.b1) issue(b + 1, cur ^ 1);
+        __syncthreads();                                      // -delta and the scaled lse of every query are visible
+
+        if (wave_on) {
+            f32x16 dk = ZERO16, dv = ZERO16;
+            // opaque copy of the wave index: the per-step LDS addresses must not be hoisted out of the sample loop (8 steps x ~6 address
+            // registers held across the loop made the kernel spill); rebuilt per step they cost a few VALU adds on a scalar
+            int wv = wave;
+            asm volatile("" : "+s"(wv));
+            // front(s): lse / -delta rows as C operands, then the S^T and dP^T MFMAs of step s.  Issued one step AHEAD of the soft-max
+            // that consumes them (two register sets), so the matrix pipe works under the VALU chain of the same wave.
+            f32x16 sxa, dpa, sxb, dpb;
+            auto front = [&](int s, f32x16& sx, f32x16& dp) {
+                const int qt = (wv + s) % NT;                 // wave-uniform
+                const char* Qt = Qs + qt * 2048;              // rows 32 qt .. of the Q image (dO: + 16384)
+                const float* lq = (const float*)(Qs + 32768 + qt * 128 + hi * 16);
+                const float* nq = (const float*)(smem + ND_OFF + qt * 128 + hi * 16);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {              // rows tile_row(4 r4 .. 4 r4 + 3, hi) are four consecutive queries
+                    const float4 d4 = *(const float4*)(nq + 8 * r4);
+                    const float4 l4 = *(const float4*)(lq + 8 * r4);
+                    dp[4 * r4] = d4.x; dp[4 * r4 + 1] = d4.y; dp[4 * r4 + 2] = d4.z; dp[4 * r4 + 3] = d4.w;
+                    sx[4 * r4] = l4.x; sx[4 * r4 + 1] = l4.y; sx[4 * r4 + 2] = l4.z; sx[4 * r4 + 3] = l4.w;
+                }
+                sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[s][0].b, id0, sx, 0, 0, 0);
+                sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[s][1].b, id1, sx, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int off = ks ? ko1 : ko0;
+                    bf16x8 qa_ = *(const bf16x8*)(Qt + off);
+                    sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa_, kf[ks], sx, 0, 0, 0);
+                    bf16x8 ga = *(const bf16x8*)(Qt + 16384 + off);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp, 0, 0, 0);
+                }
+            };
+            auto back = [&](int s, const f32x16& sx, const f32x16& dp) {
+                const int qt = (wv + s) % NT;
+                const char* Qt = Qs + qt * 2048;
+                char* slot = smem + DQ_OFF + qt * 4096;
+                uint32_t pk[8], dsk[8];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const lav_f2 e2 = mul2(sx[r], sx[r + 1], sc, sc);
+                    const float p0 = fast_exp2(e2.x), p1 = fast_exp2(e2.y);
+                    const lav_f2 dd = mul2(p0, p1, dp[r], dp[r + 1]);
+                    pk[r >> 1] = pack2(p0, p1);
+                    dsk[r >> 1] = pack2(dd.x, dd.y);
+                }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    Frag pf, df;
+                    pf.u = make_uint4(pk[4 * sl], pk[4 * sl + 1], pk[4 * sl + 2], pk[4 * sl + 3]);
+                    df.u = make_uint4(dsk[4 * sl], dsk[4 * sl + 1], dsk[4 * sl + 2], dsk[4 * sl + 3]);
+                    bf16x8 gt = tr_pair(Qt + 16384 + sl * 1024 + tr_lo, Qt + 16384 + sl * 1024 + tr_hi);
+                    dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf.b, dv, 0, 0, 0);
+                    bf16x8 qt_ = tr_pair(Qt + sl * 1024 + tr_lo, Qt + sl * 1024 + tr_hi);
+                    dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, df.b, dk, 0, 0, 0);
+                }
+                // dQ: wait until the tile's accumulator carries the s earlier contributions (wave (qt - s') mod NT added its own at its
+                // step s'), take it as the C operand, use the slot's first 2 KB as the dS^T scratch while the tile is in registers
+                f32x16 dq = ZERO16;
+                if (s > 0) {
+                    while (__builtin_amdgcn_readfirstlane(*(volatile int*)(flags + qt)) < s) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float4 c4 = *(const float4*)(slot + r4 * 1024 + lane * 16);
+                        dq[4 * r4] = c4.x; dq[4 * r4 + 1] = c4.y; dq[4 * r4 + 2] = c4.z; dq[4 * r4 + 3] = c4.w;
+                    }
+                }
+                {
+                    char* srow = slot + sw0;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        *(uint2*)((size_t)srow ^ (size_t)(r4 << 4)) = make_uint2(dsk[2 * r4], dsk[2 * r4 + 1]);
+                }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    bf16x8 dst = tr_pair(slot + sl * 1024 + tr_lo, slot + sl * 1024 + tr_hi);      // B[k = key 16 sl ..][j = query]
+                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[sl], dst, dq, 0, 0, 0);
+                }
+                if (s < NT - 1) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        *(float4*)(slot + r4 * 1024 + lane * 16) = make_float4(dq[4 * r4], dq[4 * r4 + 1], dq[4 * r4 + 2], dq[4 * r4 + 3]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) *(volatile int*)(flags + qt) = s + 1;
+                } else {
+                    const int qrel = srel_l[qt * 32 + j];
+                    if (qrel >= 0) {
+                        bf16_t* op = a.dqkv + ((long)b * a.tps + qrel) * ld + g.head * HD;
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            uint2 w;
+                            w.x = pack2(dq[r4 * 4 + 0] * a.d.scale, dq[r4 * 4 + 1] * a.d.scale);
+                            w.y = pack2(dq[r4 * 4 + 2] * a.d.scale, dq[r4 * 4 + 3] * a.d.scale);
+                            *(uint2*)(op + 8 * r4 + 4 * hi) = w;
+                        }
+                    }
+                }
+            };
+            front(0, sxa, dpa);
+#pragma unroll
+            for (int s = 0; s < NT; s += 2) {
+                if (s + 1 < NT) front(s + 1, sxb, dpb);
+                back(s, sxa, dpa);
+                if (s + 1 < NT) {
+                    if (s + 2 < NT) front(s + 2, sxa, dpa);
+                    back(s + 1, sxb, dpb);
                 }
             }
             if (k_ok) {
@@ -904,6 +1171,15 @@ int win_persistent_dbias(void* stream, const AttnArgs& a, const float* ndelta) {
 int win_persistent_bwd(void* stream, const AttnArgs& a, float* ndelta) {
     const int bs = pick_bsplit(a);
     const dim3 grid(a.d.heads * a.nWs * bs);
+    static const bool one_pass = getenv("LAV_WIN_BWD1") ? atoi(getenv("LAV_WIN_BWD1")) != 0 : true;   // probe hook: 0 = the two-pass kernels of round 3
+    if (one_pass) {
+        const size_t lds = 2 * (32768 + 1024) + 1024 + 8 * 6144 + 8 * 4096 + 1024 + 64;
+#define BWD1_(NT) { big_lds(win_bwd1<NT>, lds); hipLaunchKernelGGL(win_bwd1<NT>, grid, dim3(512), lds, (hipStream_t)stream, a, bs, ndelta); }
+        NT_SWITCH((a.N + 31) / 32, BWD1_)
+#undef BWD1_
+        if (a.dbias) return win_persistent_dbias(stream, a, ndelta);
+        return lav_check_launch("lav_attention_bwd(window, one pass)");
+    }
     const size_t lds1 = 2 * (32768 + 1024) + 8 * 6144 + 1024;
     const size_t lds2 = 2 * (32768 + 2048) + 8 * 4096 + 1024;
 #define DQ3_(NT) { big_lds(win_dq3<NT>, lds1); hipLaunchKernelGGL(win_dq3<NT>, grid, dim3(512), lds1, (hipStream_t)stream, a, bs, ndelta); }
