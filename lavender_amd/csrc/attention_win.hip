@@ -68,6 +68,18 @@ __device__ __forceinline__ bf16x8 tr_frag_k32(const char* tile, int key0, int la
     return u.v;
 }
 
+// Version flags of the dQ tiles (win_bwd1), as explicit DS instructions: through a generic pointer hipcc emits FLAT accesses and waits
+// vmcnt(0) around each -- i.e. for the whole LDS-DMA prefetch of the next sample.  An LDS serves one wave's requests in order, so a flag
+// written behind the data and a consumer that reads the flag, waits, then reads the data need no further fences.
+__device__ __forceinline__ int lds_flag_read(unsigned addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void lds_flag_write(unsigned addr, int v) {
+    asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+
 // the same fragment from two ready addresses (the two ds_read_b64_tr_b16 of a tr_frag_k32)
 __device__ __forceinline__ bf16x8 tr_pair(const char* p_lo, const char* p_hi) {
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p_lo);
@@ -591,8 +603,13 @@ __global__ __launch_bounds__(512) void win_dkv3(AttnArgs a, int bsplit, const fl
 // LDS: [2][Q 16 KB | dO 16 KB | lse 1 KB] + -delta 1 KB + strips [8][K 2 KB | V 2 KB | O 2 KB] + dQ tiles [8][4 KB] + token rows 1 KB
 //      = 148 KB.
 // ------------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* ndelta_out) {
+// PROF: s_memtime stamps of workgroup 0, waves 0 and 4 (one SIMD), third sample of the walk -> prof[wave >> 2][step][8] (tools/win_prof.py)
+#define WSTAMP(slot_, var_) do { if constexpr (PROF) { if (prof_on) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(var_) :: "memory"); \
+    if (lane == 0) prof[((wave >> 2) * NT + s) * 8 + (slot_)] = t_; } } } while (0)
+#define OSTAMP(slot_) do { if constexpr (PROF) { if (prof_on) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if (lane == 0) prof[128 + (wave >> 2) * 16 + (slot_)] = t_; } } } while (0)
+template <int NT, bool PROF = false>
+__global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* ndelta_out, unsigned long long* prof = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WinGeo g;
     if (!win_geo(a, bsplit, blockIdx.x, g)) return;
@@ -603,6 +620,7 @@ __global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* n
     char* strips = smem + STRIP_OFF;
     int* srel_l = (int*)(smem + SREL_OFF);                    // raw token rows (-1 = padded slot)
     int* flags = (int*)(smem + FLAG_OFF);                     // flags[t] = contributions added to dQ tile t so far
+    const unsigned flag0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + FLAG_OFF;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = a.C, ld = 3 * C;
@@ -646,21 +664,26 @@ __global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* n
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned strip0 = lds0 + STRIP_OFF + wave * 6144;
     const long lse_row = (long)g.ws * a.d.heads + g.head;
-    auto issue = [&](int b, int buf) {
+    // the 10 one-KB pieces a wave fetches per sample (+ the lse row, wave 0), numbered so that they can be issued a few at a time
+    auto issue_piece = [&](int b, int buf, int p) {
         const bf16_t* bq = a.qkv + (long)b * a.tps * qa.rs;
         const bf16_t* bg = a.dout + (long)b * a.tps * C;
         const bf16_t* bo = a.out + (long)b * a.tps * C;
         const unsigned d0 = lds0 + buf * BUF + wave * 2048;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            dma16(d0 + i * 1024, bq, offq[i]);
-            dma16(d0 + 16384 + i * 1024, bg, offg[i]);
-            dma16(strip0 + i * 1024, bq, offk[i]);
-            dma16(strip0 + 2048 + i * 1024, bq, offk[i] + qa.pl_b);
-            dma16(strip0 + 4096 + i * 1024, bo, offg[i]);
+        const int i = p & 1;
+        switch (p >> 1) {
+            case 0: dma16(d0 + i * 1024, bq, offq[i]); break;
+            case 1: dma16(d0 + 16384 + i * 1024, bg, offg[i]); break;
+            case 2: dma16(strip0 + i * 1024, bq, offk[i]); break;
+            case 3: dma16(strip0 + 2048 + i * 1024, bq, offk[i] + qa.pl_b); break;
+            default: dma16(strip0 + 4096 + i * 1024, bo, offg[i]); break;
         }
-        if (wave == 0)
+        if (p == 0 && wave == 0)
             dma16(lds0 + buf * BUF + 32768, a.lse + ((long)b * a.nWs * a.d.heads + lse_row) * a.Npad, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
+    };
+    auto issue = [&](int b, int buf) {
+#pragma unroll
+        for (int p = 0; p < 10; ++p) issue_piece(b, buf, p);
     };
     issue(g.b0, 0);
     dma_wait_all();
@@ -673,6 +696,8 @@ __global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* n
         const char* Sk = strips + wave * 6144;
         bf16x8 kf[2], vf[2], ktf[2];
         float dl = 0.f;
+        const bool prof_on = PROF && prof && blockIdx.x == 0 && (wave & 3) == 0 && b == g.b0 + 2;
+        OSTAMP(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int off = ks ? ko1 : ko0;
@@ -696,8 +721,15 @@ __global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* n
         if (tid < 256) { float* ll = (float*)(Qs + 32768); ll[tid] = -ll[tid] * inv_sc; }
         if (tid < 8) flags[tid] = 0;
         lds_wait_all();                                       // the strips are in registers: their LDS image may be overwritten
-        if (b + 1 < g.b1) issue(b + 1, cur ^ 1);
+        OSTAMP(1);
+        // Next sample's operands: issued ALL AT ONCE here, every CU's burst hits memory together and the issue itself blocks for
+        // 4-8 k cycles (88 KB per CU at the ~12 B/clk/CU the chip sustains: profiles/r05_win_bwd1.md); an active wave spreads its pieces
+        // over the steps instead (its strips are in registers, the other image buffer is idle: any time in the sample is legal).
+        const bool more = b + 1 < g.b1;
+        if (more && !wave_on) issue(b + 1, cur ^ 1);
+        OSTAMP(2);
         __syncthreads();                                      // -delta and the scaled lse of every query are visible
+        OSTAMP(3);
 
         if (wave_on) {
             f32x16 dk = ZERO16, dv = ZERO16;
@@ -731,11 +763,12 @@ __global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* n
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp, 0, 0, 0);
                 }
             };
-            auto back = [&](int s, const f32x16& sx, const f32x16& dp) {
+            auto back = [&](int s, f32x16& sx, const f32x16& dp) {
                 const int qt = (wv + s) % NT;
                 const char* Qt = Qs + qt * 2048;
                 char* slot = smem + DQ_OFF + qt * 4096;
                 uint32_t pk[8], dsk[8];
+                WSTAMP(0, sx[0]);
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const lav_f2 e2 = mul2(sx[r], sx[r + 1], sc, sc);
@@ -744,6 +777,7 @@ __global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* n
                     pk[r >> 1] = pack2(p0, p1);
                     dsk[r >> 1] = pack2(dd.x, dd.y);
                 }
+                WSTAMP(1, dsk[7]);
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
                     Frag pf, df;
@@ -752,37 +786,41 @@ __global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* n
                     bf16x8 gt = tr_pair(Qt + 16384 + sl * 1024 + tr_lo, Qt + 16384 + sl * 1024 + tr_hi);
                     dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf.b, dv, 0, 0, 0);
                     bf16x8 qt_ = tr_pair(Qt + sl * 1024 + tr_lo, Qt + sl * 1024 + tr_hi);
+                    if (sl == 1) WSTAMP(2, qt_);
                     dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, df.b, dk, 0, 0, 0);
                 }
                 // dQ: wait until the tile's accumulator carries the s earlier contributions (wave (qt - s') mod NT added its own at its
                 // step s'), take it as the C operand, use the slot's first 2 KB as the dS^T scratch while the tile is in registers
                 f32x16 dq = ZERO16;
                 if (s > 0) {
-                    while (__builtin_amdgcn_readfirstlane(*(volatile int*)(flags + qt)) < s) __builtin_amdgcn_s_sleep(1);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    while (lds_flag_read(flag0 + qt * 4) < s) __builtin_amdgcn_s_sleep(1);
+                    WSTAMP(3, dsk[0]);
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const float4 c4 = *(const float4*)(slot + r4 * 1024 + lane * 16);
                         dq[4 * r4] = c4.x; dq[4 * r4 + 1] = c4.y; dq[4 * r4 + 2] = c4.z; dq[4 * r4 + 3] = c4.w;
                     }
+                    WSTAMP(4, dq[15]);
                 }
                 {
-                    char* srow = slot + sw0;
+                    const int so = DQ_OFF + qt * 4096 + sw0;  // offsets, not pointers: an XOR on a pointer value loses the LDS address space (flat stores)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4)
-                        *(uint2*)((size_t)srow ^ (size_t)(r4 << 4)) = make_uint2(dsk[2 * r4], dsk[2 * r4 + 1]);
+                        *(uint2*)(smem + (so ^ (r4 << 4))) = make_uint2(dsk[2 * r4], dsk[2 * r4 + 1]);
                 }
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
                     bf16x8 dst = tr_pair(slot + sl * 1024 + tr_lo, slot + sl * 1024 + tr_hi);      // B[k = key 16 sl ..][j = query]
+                    if (sl == 1) WSTAMP(5, dst);
                     dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[sl], dst, dq, 0, 0, 0);
                 }
+                WSTAMP(6, dq[0]);
                 if (s < NT - 1) {
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4)
                         *(float4*)(slot + r4 * 1024 + lane * 16) = make_float4(dq[4 * r4], dq[4 * r4 + 1], dq[4 * r4 + 2], dq[4 * r4 + 3]);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0) *(volatile int*)(flags + qt) = s + 1;
+                    lds_flag_write(flag0 + qt * 4, s + 1);      // behind the tile in this wave's (in-order) LDS queue: no wait needed
+                    WSTAMP(7, dsk[1]);
                 } else {
                     const int qrel = srel_l[qt * 32 + j];
                     if (qrel >= 0) {
@@ -797,13 +835,22 @@ __global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* n
                     }
                 }
             };
+            auto dma_step = [&](int s) {                      // pieces [10 s / NT, 10 (s + 1) / NT) of the next sample
+                if (more) {
+#pragma unroll
+                    for (int p = 0; p < 10; ++p)
+                        if (p >= 10 * s / NT && p < 10 * (s + 1) / NT) issue_piece(b + 1, cur ^ 1, p);
+                }
+            };
             front(0, sxa, dpa);
 #pragma unroll
             for (int s = 0; s < NT; s += 2) {
                 if (s + 1 < NT) front(s + 1, sxb, dpb);
+                dma_step(s);
                 back(s, sxa, dpa);
                 if (s + 1 < NT) {
                     if (s + 2 < NT) front(s + 2, sxa, dpa);
+                    dma_step(s + 1);
                     back(s + 1, sxb, dpb);
                 }
             }
@@ -822,8 +869,11 @@ __global__ __launch_bounds__(512) void win_bwd1(AttnArgs a, int bsplit, float* n
                 }
             }
         }
+        OSTAMP(4);
         dma_wait_all();
+        OSTAMP(5);
         __syncthreads();
+        OSTAMP(6);
     }
 }
 
@@ -1168,13 +1218,20 @@ int win_persistent_dbias(void* stream, const AttnArgs& a, const float* ndelta) {
     return lav_check_launch("lav_attention_bwd_bias(window, persistent)");
 }
 
+static unsigned long long* g_win_prof = nullptr;            // probe hook (tools/win_prof.py): device buffer for the stamped build of win_bwd1<8>
+extern "C" void lav_probe_win_prof(void* buf) { g_win_prof = (unsigned long long*)buf; }
 int win_persistent_bwd(void* stream, const AttnArgs& a, float* ndelta) {
     const int bs = pick_bsplit(a);
     const dim3 grid(a.d.heads * a.nWs * bs);
     static const bool one_pass = getenv("LAV_WIN_BWD1") ? atoi(getenv("LAV_WIN_BWD1")) != 0 : true;   // probe hook: 0 = the two-pass kernels of round 3
     if (one_pass) {
         const size_t lds = 2 * (32768 + 1024) + 1024 + 8 * 6144 + 8 * 4096 + 1024 + 64;
-#define BWD1_(NT) { big_lds(win_bwd1<NT>, lds); hipLaunchKernelGGL(win_bwd1<NT>, grid, dim3(512), lds, (hipStream_t)stream, a, bs, ndelta); }
+        if (g_win_prof && (a.N + 31) / 32 == 8) {
+            big_lds(win_bwd1<8, true>, lds);
+            hipLaunchKernelGGL((win_bwd1<8, true>), grid, dim3(512), lds, (hipStream_t)stream, a, bs, ndelta, g_win_prof);
+            return lav_check_launch("lav_attention_bwd(window, one pass, stamped)");
+        }
+#define BWD1_(NT) { big_lds(win_bwd1<NT>, lds); hipLaunchKernelGGL(win_bwd1<NT>, grid, dim3(512), lds, (hipStream_t)stream, a, bs, ndelta, (unsigned long long*)nullptr); }
         NT_SWITCH((a.N + 31) / 32, BWD1_)
 #undef BWD1_
         if (a.dbias) return win_persistent_dbias(stream, a, ndelta);
