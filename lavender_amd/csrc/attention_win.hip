@@ -180,17 +180,16 @@ __global__ __launch_bounds__(512) void win_fwd3(AttnArgs a, int bsplit) {
         offv[i] = offq[i] + 2 * qa.pl_b;
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto issue = [&](int b, int buf) {
+    auto issue_piece = [&](int b, int buf, int p) {          // piece p of the wave's six one-KB pieces of a sample
         const bf16_t* base = a.qkv + (long)b * a.tps * qa.rs;
         const unsigned d0 = lds0 + buf * BUF + wave * 2048;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            dma16(d0 + i * 1024, base, offq[i]);
-            dma16(d0 + 16384 + i * 1024, base, offk[i]);
-            dma16(d0 + 32768 + i * 1024, base, offv[i]);
-        }
+        const int i = p & 1;
+        if ((p >> 1) == 0) dma16(d0 + i * 1024, base, offq[i]);
+        else if ((p >> 1) == 1) dma16(d0 + 16384 + i * 1024, base, offk[i]);
+        else dma16(d0 + 32768 + i * 1024, base, offv[i]);
     };
-    issue(g.b0, 0);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) issue_piece(g.b0, 0, p);
     dma_wait_all();
     __syncthreads();
 
@@ -199,7 +198,16 @@ __global__ __launch_bounds__(512) void win_fwd3(AttnArgs a, int bsplit) {
         const char* Qs = smem + cur * BUF;
         const char* Ks = Qs + 16384;
         const char* Vs = Qs + 32768;
-        if (b + 1 < g.b1) issue(b + 1, cur ^ 1);
+        // the next sample's pieces go out a few per key tile, not as one burst at the top (all CUs bursting together block in the issue
+        // for thousands of cycles: profiles/r05_win_bwd1.md)
+        const bool more = b + 1 < g.b1;
+        auto dma_step = [&](int t) {
+            if (more) {
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+                    if (p >= 6 * t / NT && p < 6 * (t + 1) / NT) issue_piece(b + 1, cur ^ 1, p);
+            }
+        };
         bf16x8 qf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(Qs + krow_off<HD>(q, ks * 2 + hi));
@@ -256,9 +264,11 @@ __global__ __launch_bounds__(512) void win_fwd3(AttnArgs a, int bsplit) {
 #pragma unroll
         for (int t = 0; t < NT; t += 2) {
             if (t + 1 < NT) qk(t + 1, sb, kb, ka);
+            dma_step(t);
             soft(t, sa);
             if (t + 1 < NT) {
                 if (t + 2 < NT) qk(t + 2, sa, ka, kb);
+                dma_step(t + 1);
                 soft(t + 1, sb);
             }
         }
@@ -939,22 +949,22 @@ __global__ __launch_bounds__(512) void win_dbias3(AttnArgs a, int bsplit, const 
     offs[1] = dma_off(srel_l, qh * 8 + wave, lane, C, g.head * HD);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const long lse_row = (long)g.ws * a.d.heads + g.head;
-    auto issue = [&](int b, int buf) {
+    auto issue_piece = [&](int b, int buf, int p) {          // piece p of the wave's six one-KB pieces of a sample (+ lse / -delta rows)
         const bf16_t* bq = a.qkv + (long)b * a.tps * qa.rs;
         const bf16_t* bg = a.dout + (long)b * a.tps * C;
         const unsigned d0 = lds0 + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            dma16(d0 + wave * 2048 + i * 1024, bq, offk[i]);
-            dma16(d0 + 16384 + wave * 2048 + i * 1024, bq, offk[i] + qa.pl_b);
+        if (p < 2) dma16(d0 + wave * 2048 + p * 1024, bq, offk[p]);
+        else if (p < 4) dma16(d0 + 16384 + wave * 2048 + (p - 2) * 1024, bq, offk[p - 2] + qa.pl_b);
+        else if (p == 4) dma16(d0 + 32768 + wave * 1024, bq, offs[0]);
+        else {
+            dma16(d0 + 32768 + 8192 + wave * 1024, bg, offs[1]);
+            const long lo = ((long)b * a.nWs * a.d.heads + lse_row) * a.Npad;
+            if (wave == 0) dma16(d0 + 49152, a.lse + lo, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
+            if (wave == 1) dma16(d0 + 49152 + 1024, ndelta_in + lo, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
         }
-        dma16(d0 + 32768 + wave * 1024, bq, offs[0]);
-        dma16(d0 + 32768 + 8192 + wave * 1024, bg, offs[1]);
-        const long lo = ((long)b * a.nWs * a.d.heads + lse_row) * a.Npad;
-        if (wave == 0) dma16(d0 + 49152, a.lse + lo, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
-        if (wave == 1) dma16(d0 + 49152 + 1024, ndelta_in + lo, (unsigned)(min(lane * 4, a.Npad - 4) * 4));
     };
-    issue(g.b0, 0);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) issue_piece(g.b0, 0, p);
     dma_wait_all();
     __syncthreads();
 
@@ -966,7 +976,12 @@ __global__ __launch_bounds__(512) void win_dbias3(AttnArgs a, int bsplit, const 
         const char* Sg = Sq + 8192;
         const float* lse_l = (const float*)(Ks + 49152);
         const float* ndl_l = lse_l + 256;
-        if (b + 1 < g.b1) issue(b + 1, cur ^ 1);
+        // next sample's pieces: spread over the key tiles of an active wave instead of one burst at the top (profiles/r05_win_bwd1.md)
+        const bool more = b + 1 < g.b1;
+        if (more && !strip_on) {
+#pragma unroll
+            for (int p = 0; p < 6; ++p) issue_piece(b + 1, cur ^ 1, p);
+        }
         if (strip_on) {
             bf16x8 qf[2], dof[2];
 #pragma unroll
@@ -982,7 +997,11 @@ __global__ __launch_bounds__(512) void win_dbias3(AttnArgs a, int bsplit, const 
 #pragma unroll
             for (int i = 0; i < NK; ++i) {
                 const int t = kh * 4 + i;
-                if (t >= NT) break;                          // wave-uniform
+                if (more) {                                  // (before the tile-count exit: every piece must go out)
+                    if (i < 2) { issue_piece(b + 1, cur ^ 1, 2 * i); issue_piece(b + 1, cur ^ 1, 2 * i + 1); }
+                    else issue_piece(b + 1, cur ^ 1, 2 + i);
+                }
+                if (t >= NT) continue;                       // wave-uniform
                 const f32x16 z = ZERO16;
                 f32x16 s, dp = ndl;
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[i][0].b, id0, z, 0, 0, 0);
