@@ -4,15 +4,26 @@
  * point below replaces the device work that a reference torch op sequence does; the reference
  * file:line it stands in for is cited per function (paths relative to the reference root).
  *
- * Conventions:
+ * Conventions, as the code really behaves (ABI 6):
  *   - C linkage, POD arguments, no torch types.  Every function returns 0 on success or a negative
- *     LAV_E_* code; lav_last_error() returns a message for the calling thread.  Nothing throws/exits.
- *   - All data pointers are DEVICE pointers owned by the caller; kernels never allocate or free.
- *   - `stream` is a hipStream_t passed as void*.  Functions only enqueue work (asynchronous), keep no
- *     global mutable state, and may be called concurrently on different streams.
+ *     LAV_E_* code (-1 argument, -2 launch, -3 unsupported, -4 workspace); lav_last_error() returns a message for the calling
+ *     thread.  Nothing throws/exits.
+ *   - All data pointers are DEVICE pointers owned by the caller.  Scratch is caller-owned too: split-K partial tiles, the LayerNorm
+ *     column partials and the deferred-reduction arena live in per-(stream, kind) WORKSPACES that the caller registers with
+ *     lav_set_workspace (sizes from lav_workspace_bytes).  Only when nothing was registered does the library make ONE internal
+ *     allocation per (stream, kind) on first use -- a documented fallback for tools and tests; it is never grown, re-made or freed.
+ *     A call that needs more than the registered / internal size fails with LAV_E_WORKSPACE and a message that names the size.
+ *     No entry point calls hipDeviceSynchronize, hipStreamSynchronize or hipFree.
+ *   - `stream` is a hipStream_t passed as void*.  Functions only enqueue work (asynchronous).  Mutable library state is per stream
+ *     (workspace table, deferred LayerNorm queues) and guarded by mutexes, so different host threads may call concurrently on
+ *     DIFFERENT streams; calls on one stream must come from one thread at a time (they are ordered by that stream).
+ *     What is process-wide: lav_gemm_select (a probe hook, see there) and the LAV_* environment switches listed at the end of this
+ *     header, read once on first use; they choose between equivalent kernels and exist for A/B measurements.
+ *   - One device per process (one rank per GPU): every launch checks it.
  *   - bf16 tensors are raw uint16 bit patterns, row-major; "ld*" are leading dimensions in ELEMENTS.
- *   - Gradient accumulators (dW, dbias, dgamma, ...) are fp32 and are ACCUMULATED INTO with atomics:
- *     the caller zeroes them once per step (this is what lets the MTM and VTM passes share weights).
+ *   - Gradient accumulators (dW, dbias, dgamma, ...) are fp32 and are ACCUMULATED INTO (read-modify-write by the owning tile or
+ *     reduction pass, atomics for small vectors): the caller zeroes them once per step (this is what lets the MTM and VTM passes
+ *     share weights).
  */
 #ifndef LAVENDER_HIP_H
 #define LAVENDER_HIP_H
@@ -24,7 +35,22 @@ extern "C" {
 #endif
 
 const char* lav_last_error(void);
-int lav_abi_version(void);   /* 5: lav_gemm_tn_grouped (+ lav_*_bwd_desc.group_splits), fp16 rows (out_mode 3, residual_f32 / x_f32 = 2, lav_bert_layer_desc.stream_f16), lav_layernorm_set_defer / lav_layernorm_flush, lav_attn_desc.bias_map / lav_attention_build_bias_map; 4: lav_gemm_epilogue.c_pad_writable; 3: a_rowmap / res_rowmap / res_ln_*; 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
+
+/* Scratch workspaces (see the conventions above).  kind:
+ *   LAV_WS_SPLITK       fp32 partial tiles of split-K GEMMs issued on `stream`: a call needs splits x tiles x tile bytes (at most
+ *                       splits * ceil(M / 256) * ceil(N / 256) * 256 KiB; a grouped launch the sum over its jobs)
+ *   LAV_WS_LN_PARTIALS  per-block column partials of a LayerNorm backward that finishes at once: 3 * min(768, row blocks) * C * 4 bytes
+ *   LAV_WS_LN_DEFER     bump arena of the deferred LayerNorm column reductions of `stream` (lav_layernorm_set_defer): any size; a
+ *                       reduction that does not fit finishes at once through LAV_WS_LN_PARTIALS
+ * lav_workspace_bytes(kind): the size that covers every shape of the shipped configurations (cfg2 / cfg4 / cfg5): 256 / 32 / 384 MiB.
+ * lav_set_workspace(stream, kind, ptr, bytes): `ptr` (256-byte aligned, caller-owned, alive until replaced) serves every later call on
+ * that stream; (NULL, 0) un-registers.  Replace a workspace only when no enqueued work of that stream still uses the old one. */
+#define LAV_WS_SPLITK 0
+#define LAV_WS_LN_PARTIALS 1
+#define LAV_WS_LN_DEFER 2
+size_t lav_workspace_bytes(int kind);
+int lav_set_workspace(void* stream, int kind, void* ptr, size_t bytes);
+int lav_abi_version(void);   /* 6: lav_workspace_bytes / lav_set_workspace, lav_layernorm_set_defer per stream + lav_layernorm_flush_all, lav_ln_bwd_extra.finish_stream removed, LAV_E_WORKSPACE; 5: lav_gemm_tn_grouped (+ lav_*_bwd_desc.group_splits), fp16 rows (out_mode 3, residual_f32 / x_f32 = 2, lav_bert_layer_desc.stream_f16), lav_layernorm_set_defer / lav_layernorm_flush, lav_attn_desc.bias_map / lav_attention_build_bias_map; 4: lav_gemm_epilogue.c_pad_writable; 3: a_rowmap / res_rowmap / res_ln_*; 2: residual_f32, lav_ln_f32, causal_from, lav_scale_by_scalar, lav_v_* validation entries, lavender_pipeline.h */
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM with fused epilogue.  Replaces every nn.Linear on the path (video_swin.py:73-79,137-139,
@@ -41,8 +67,7 @@ int lav_abi_version(void);   /* 5: lav_gemm_tn_grouped (+ lav_*_bwd_desc.group_s
  * next multiple of 8 (their last 16-byte chunk is read whole).
  * Split-K (`splits` > 1): layout 2 with out_mode 2 (weight gradients), or layouts 0/1 with a bf16 output, no
  * epilogue and N % 8 == 0 (long-K problems with few output tiles, e.g. d_hidden = dlogits . W_dec).  Partial tiles
- * go to an fp32 workspace owned by the calling stream (one per stream, up to 8 streams; grown on demand) and are
- * summed by a reduction pass on that stream.
+ * go to the stream's LAV_WS_SPLITK workspace and are summed by a reduction pass on that stream.
  */
 typedef struct lav_gemm_epilogue {
     const float* bias;        /* [N] fp32 or NULL */
@@ -158,9 +183,6 @@ typedef struct lav_ln_bwd_extra {
     float dropout_p; uint32_t seed;
     float* colsum;
     int x_f32;                /* the saved LayerNorm input x is fp32 (1) or fp16 (2) (see lav_ln_f32) */
-    void* finish_stream;      /* NULL or a hipStream_t: the column reduction that produces dgamma / dbeta / colsum (parameter gradients,
-                                 not needed by the dy -> dx chain) is enqueued THERE, ordered after the row pass by an event; `stream`
-                                 only runs the row pass.  The caller joins finish_stream before it reads those three vectors */
 } lav_ln_bwd_extra;
 
 int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, long lddy, const void* x, long ldx,
@@ -168,14 +190,18 @@ int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, long lddy, 
                       const void* add_in, long ldadd, void* dx, long lddx, float* dgamma, float* dbeta,
                       const lav_ln_bwd_extra* extra);
 
-/* Deferred column reductions.  lav_layernorm_set_defer(1): every following lav_layernorm_bwd (also the ones the stage-level entries issue)
- * only runs its row pass -- dx (and dx2) are complete as before -- and QUEUES the reduction of its per-block partials into dgamma / dbeta /
- * colsum; lav_layernorm_flush(stream) completes all queued reductions of that stream in ONE launch.  The three vectors are parameter
- * gradients (nn.LayerNorm weight / bias, the bias of the dense layer in front): nothing in the dy -> dx chain reads them, so the caller
- * flushes where gradients become final (before the gradient exchange, the norm, the optimizer).  A call flushes by itself when 48
- * reductions are queued or its scratch arena is full.  Returns the previous mode / an error code.  Default: off. */
-int lav_layernorm_set_defer(int on);
+/* Deferred column reductions, per stream.  lav_layernorm_set_defer(stream, 1): every following lav_layernorm_bwd on that stream (also
+ * the ones the stage-level entries issue) only runs its row pass -- dx (and dx2) are complete as before -- and QUEUES the reduction of its
+ * per-block partials (kept in the stream's LAV_WS_LN_DEFER workspace) into dgamma / dbeta / colsum.  lav_layernorm_flush(stream) completes
+ * all queued reductions of that stream in ONE launch on it; lav_layernorm_flush_all(join_stream) does so for EVERY stream, each on its
+ * own stream, and makes join_stream wait (event) for the others -- use it where the stream that ran the backward is not known.  The three
+ * vectors are parameter gradients (nn.LayerNorm weight / bias, the bias of the dense layer in front): nothing in the dy -> dx chain reads
+ * them, so the caller flushes where gradients become final (before the gradient exchange, the norm, the optimizer).  A call flushes by
+ * itself when 48 reductions are queued or the arena is full; switching the mode off flushes.  set_defer returns the previous mode (0 / 1)
+ * or an error code.  Default: off. */
+int lav_layernorm_set_defer(void* stream, int on);
 int lav_layernorm_flush(void* stream);
+int lav_layernorm_flush_all(void* join_stream);
 
 /* Row-wise helper: out = row_scale[row/rpg] * gelu'(gelu_in) * dropout(seed; in), column sums into colsum.
  * Produces a dense-branch gradient from a residual-stream gradient (inverse of the GEMM epilogue's dropout /
@@ -468,6 +494,20 @@ typedef struct lav_swin_block_bwd_desc {
 } lav_swin_block_bwd_desc;
 /* side_stream as in lav_bert_layer_bwd; the relative-position-bias-table gradient runs there too when lav_attention_bias_split(attn). */
 int lav_swin_block_bwd(void* stream, void* side_stream, const lav_swin_block_bwd_desc* d);
+
+/* ---------------------------------------------------------------------------------------------
+ * Process-wide probe switches: environment variables read ONCE by the library on first use (not part of the contract; every setting
+ * computes the same results up to fp32 summation order unless stated).  They exist so that tools/ and profiles/ can A/B a kernel
+ * choice on one box.
+ *   LAV_GEMM_TN_KIND (0 / 1: weight-gradient tiles of at most 128x128 / 256x128), LAV_GEMM_PP_TN (0: no ping-pong 256x256
+ *   weight-gradient kernel), LAV_GEMM_TN_MINM (fewest output rows for the 256-row weight-gradient tiles, default 160),
+ *   LAV_GEMM_TN_GROUP (0: grouped weight-gradient launches run job by job), LAV_GEMM_GROUP_N (column-group width of the 256x256 tile
+ *   walk), LAV_GEMM_H192 / LAV_GEMM_H192L (0: no 192-row tiles / no loader waves), LAV_NT_STORES (bit 0: GELU' stored non-temporally,
+ *   bit 2: loaded non-temporally; cross-entropy gradient stores), LAV_GEMM_DBG (timing ablations of the 256x256 kernel: WRONG results),
+ *   LAV_LN_ATOMIC_FLUSH (LayerNorm backward column sums by per-block atomics), LAV_WIN_BWD1 (0: window attention backward as the two
+ *   round-3 passes instead of the one-pass kernel), LAV_WINL / LAV_SEQL (0: large windows / long sequences on the generic kernels).
+ * lav_gemm_select(which, value) changes the GEMM ones of these at run time (same caveat: process-wide, for probes).
+ * --------------------------------------------------------------------------------------------- */
 
 #ifdef __cplusplus
 }

@@ -44,7 +44,7 @@ class LnGather(C.Structure):
 
 class LnBwdExtra(C.Structure):
     _fields_ = [("dx2", vp), ("lddx2", i64), ("row_scale", vp), ("rows_per_group", i32), ("dropout_p", f32),
-                ("seed", u32), ("colsum", vp), ("x_f32", i32), ("finish_stream", vp)]
+                ("seed", u32), ("colsum", vp), ("x_f32", i32)]
 
 
 class LnF32(C.Structure):
@@ -103,8 +103,11 @@ _SIGS = {
     "lav_bert_layer_bwd": (i32, [vp, vp, P(BertLayerBwdDesc)]),
     "lav_swin_block_fwd": (i32, [vp, P(SwinBlockDesc)]),
     "lav_swin_block_bwd": (i32, [vp, vp, P(SwinBlockBwdDesc)]),
-    "lav_layernorm_set_defer": (i32, [i32]),
+    "lav_layernorm_set_defer": (i32, [vp, i32]),
     "lav_layernorm_flush": (i32, [vp]),
+    "lav_layernorm_flush_all": (i32, [vp]),
+    "lav_workspace_bytes": (C.c_size_t, [i32]),
+    "lav_set_workspace": (i32, [vp, i32, vp, C.c_size_t]),
     "lav_layernorm_fwd": (i32, [vp, i32, i32, vp, i64, P(LnGather), vp, vp, f32, vp, i64, vp, vp, P(LnF32)]),
     "lav_layernorm_bwd": (i32, [vp, i32, i32, vp, i64, vp, i64, P(LnGather), vp, vp, vp, vp, i64, vp, i64, vp, vp,
                                 P(LnBwdExtra)]),
@@ -180,6 +183,12 @@ for _name, (_res, _args) in {**_SIGS, **_PIPE_SIGS}.items():
         raise ImportError(f"{LIB_PATH} does not export {_name}; rebuild it") from e
     _f.restype = _res
     _f.argtypes = _args
+
+
+ABI_VERSION = 6
+if lib.lav_abi_version() != ABI_VERSION:  # pragma: no cover
+    raise ImportError(f"{LIB_PATH} has ABI version {lib.lav_abi_version()}, this package binds version {ABI_VERSION} (descriptor layouts differ): "
+                      "rebuild it with `make -C <repo root>` or `python -c 'import __graft_entry__ as g; g.build()'`")
 
 
 def check(rc, what=""):

@@ -703,6 +703,9 @@ extern "C" int lav_attention_fwd(void* stream, const lav_attn_desc* d, const voi
     if (int rc = attn_setup(d, a, problems)) return rc;
     LAV_REQUIRE(qkv && out, "lav_attention_fwd: null pointer");
     LAV_REQUIRE(!d->qkv_headmajor || (d->mode == 0 && d->comb && d->head_dim == 32), "lav_attention_fwd: qkv_headmajor needs window mode with the precomputed tables (N <= 256, head_dim 32)");
+    // head-major operand offsets are 32-bit byte offsets from the first token row: [q | k | v][head] planes of the WHOLE batch
+    LAV_REQUIRE(!d->qkv_headmajor || 6L * d->heads * d->head_dim * d->B * d->D * d->H * d->W < (1L << 32), "lav_attention_fwd: head-major qkv of %ld bytes exceeds the 4 GiB the window kernels address with 32-bit offsets",
+                6L * d->heads * d->head_dim * d->B * d->D * d->H * d->W);
     a.qkv = (const bf16_t*)qkv; a.o_w = (bf16_t*)out; a.lse = lse;
     if (d->mode == 0 && d->comb) return win_persistent_fwd(stream, a);
     if (winl_supported(a)) return winl_fwd_launch(stream, a, problems);
@@ -737,6 +740,9 @@ extern "C" int lav_attention_bwd(void* stream, const lav_attn_desc* d, const voi
     if (int rc = attn_setup(d, a, problems)) return rc;
     LAV_REQUIRE(qkv && out && dout && lse && dqkv, "lav_attention_bwd: null pointer");
     LAV_REQUIRE(!d->qkv_headmajor || (d->mode == 0 && d->comb && d->head_dim == 32), "lav_attention_bwd: qkv_headmajor needs window mode with the precomputed tables (N <= 256, head_dim 32)");
+    // head-major operand offsets are 32-bit byte offsets from the first token row: [q | k | v][head] planes of the WHOLE batch
+    LAV_REQUIRE(!d->qkv_headmajor || 6L * d->heads * d->head_dim * d->B * d->D * d->H * d->W < (1L << 32), "lav_attention_bwd: head-major qkv of %ld bytes exceeds the 4 GiB the window kernels address with 32-bit offsets",
+                6L * d->heads * d->head_dim * d->B * d->D * d->H * d->W);
     a.qkv = (const bf16_t*)qkv; a.out = (const bf16_t*)out; a.dout = (const bf16_t*)dout; a.lse = (float*)lse;
     a.dqkv = (bf16_t*)dqkv; a.dbias = dbias_table;
     float* delta = (float*)lse + (size_t)problems * d->heads * a.Npad;
@@ -792,6 +798,9 @@ extern "C" int lav_attention_bwd_bias(void* stream, const lav_attn_desc* d, cons
     if (int rc = attn_setup(d, a, problems)) return rc;
     LAV_REQUIRE(qkv && dout && lse && dbias_table, "lav_attention_bwd_bias: null pointer");
     LAV_REQUIRE(!d->qkv_headmajor || (d->mode == 0 && d->comb && d->head_dim == 32), "lav_attention_bwd_bias: qkv_headmajor needs window mode with the precomputed tables (N <= 256, head_dim 32)");
+    // head-major operand offsets are 32-bit byte offsets from the first token row: [q | k | v][head] planes of the WHOLE batch
+    LAV_REQUIRE(!d->qkv_headmajor || 6L * d->heads * d->head_dim * d->B * d->D * d->H * d->W < (1L << 32), "lav_attention_bwd_bias: head-major qkv of %ld bytes exceeds the 4 GiB the window kernels address with 32-bit offsets",
+                6L * d->heads * d->head_dim * d->B * d->D * d->H * d->W);
     a.qkv = (const bf16_t*)qkv; a.dout = (const bf16_t*)dout; a.lse = (float*)lse; a.dbias = dbias_table;
     if (d->mode == 0 && !d->comb && winl_supported(a)) return winl_dbias_launch(stream, a, problems, lse + (size_t)problems * d->heads * a.Npad);
     LAV_REQUIRE(d->mode == 0 && d->comb, "lav_attention_bwd_bias: window mode on the persistent (N <= 256, tables given) or large-window (N <= 768) path only");

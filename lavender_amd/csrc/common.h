@@ -16,9 +16,17 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define LAV_E_ARG (-1)
 #define LAV_E_LAUNCH (-2)
 #define LAV_E_UNSUPPORTED (-3)
+#define LAV_E_WORKSPACE (-4)
 
 extern "C" void lav_set_error(const char* fmt, ...);
 int lav_check_launch(const char* what);
+// scratch workspaces (runtime.cpp): caller-registered (lav_set_workspace) or one internal allocation per (stream, kind); nullptr + lav_set_error when
+// `need` exceeds what is there (never re-allocated, no device synchronisation)
+#define LAV_WS_SPLITK 0
+#define LAV_WS_LN_PARTIALS 1
+#define LAV_WS_LN_DEFER 2
+#define LAV_WS_KINDS 3
+void* lav_ws_get(void* stream, int kind, size_t need, size_t* cap);
 
 #define LAV_REQUIRE(cond, ...)                 \
     do {                                       \

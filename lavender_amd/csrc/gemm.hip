@@ -1472,23 +1472,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
     *(uint4*)(C + (long)row * ldc + col) = pack8(v);
 }
 
-// split-K workspaces, one per stream that issues split-K GEMMs (the product uses two: the main stream and the
-// weight-gradient side stream); grown on demand.  Calls on the SAME stream are ordered, so they can share a buffer.
-struct SplitKWs { void* stream; float* ptr; size_t bytes; };
-static SplitKWs g_splitk[8] = {};
-static float* splitk_workspace(void* stream, size_t bytes) {
-    SplitKWs* e = nullptr;
-    for (auto& w : g_splitk) if (w.ptr && w.stream == stream) { e = &w; break; }
-    if (!e) for (auto& w : g_splitk) if (!w.ptr) { e = &w; e->stream = stream; break; }
-    if (!e) e = &g_splitk[0];                            // more than 8 streams: share (callers must then order those streams)
-    if (bytes > e->bytes) {
-        if (e->ptr) { (void)hipDeviceSynchronize(); (void)hipFree(e->ptr); e->ptr = nullptr; e->bytes = 0; }
-        size_t want = bytes < ((size_t)256 << 20) ? ((size_t)256 << 20) : bytes + bytes / 2;   // 256 MB up front: no re-allocation once the step runs
-        if (hipMalloc((void**)&e->ptr, want) != hipSuccess) { (void)hipGetLastError(); e->ptr = nullptr; return nullptr; }
-        e->bytes = want;
-    }
-    return e->ptr;
-}
+// split-K partial tiles live in the stream's LAV_WS_SPLITK workspace (runtime.cpp: registered by the caller with lav_set_workspace, or one internal
+// allocation per stream).  Calls on the SAME stream are ordered, so they share it.
+static float* splitk_workspace(void* stream, size_t bytes) { return (float*)lav_ws_get(stream, LAV_WS_SPLITK, bytes, nullptr); }
 
 static const int lav_gemm_tn_kind = getenv("LAV_GEMM_TN_KIND") ? atoi(getenv("LAV_GEMM_TN_KIND")) : -1;   // probe hook: 0 = 128x128 only, 1 = at most 256x128, default = largest tile that fits
 static bool lav_gemm_pp_tn = getenv("LAV_GEMM_PP_TN") ? atoi(getenv("LAV_GEMM_PP_TN")) != 0 : true;   // ping-pong kernel for the 256x256 weight-gradient tiles
@@ -1660,7 +1646,7 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
         const int ws_tiles = ((M + rpt - 1) / rpt) * ((N + BN - 1) / BN);
         if (sk) {
             g.ws = splitk_workspace(stream, (size_t)splits * ws_tiles * rpt * BN * sizeof(float));
-            LAV_REQUIRE(g.ws, "lav_gemm_bf16: split-K workspace allocation failed");
+            if (!g.ws) return LAV_E_WORKSPACE;               // message set by lav_ws_get
             g.ws_tiles = ws_tiles;
         }
         if (sk_huge) {
@@ -1711,7 +1697,8 @@ extern "C" int lav_gemm_bf16(void* stream, int layout, int M, int N, int K, cons
             if (splits == 1) g.owner = 1;
             else if ((N % 4) == 0 && (ldc % 4) == 0) {
                 float* ws = splitk_workspace(stream, (size_t)splits * ws_tiles * rpt * BN * sizeof(float));
-                if (ws) { g.ws = ws; g.ws_tiles = ws_tiles; reduce = true; }
+                if (!ws) return LAV_E_WORKSPACE;             // message set by lav_ws_get
+                g.ws = ws; g.ws_tiles = ws_tiles; reduce = true;
             }
         }
         if (kind == 2 && lav_gemm_pp_tn && (K % PP_BK) == 0 && (kps % PP_BK) == 0 &&
@@ -1775,8 +1762,7 @@ extern "C" int lav_gemm_tn_grouped(void* stream, int n_jobs, const lav_gemm_tn_j
     GemmGroup G;
     memset(&G, 0, sizeof(G));
     G.n = n_jobs;
-    static const int tn_walk = getenv("LAV_TN_WALK") ? atoi(getenv("LAV_TN_WALK")) : 3;   // probe hook for the A/B of profiles/r05_dw_walk.md: 0 = the round-4 walk
-    G.walk = tn_walk;
+    G.walk = 3;                                              // launch-wide XCD runs, short-dimension-fastest tiles (profiles/r05_dw_walk.md; 0 = the round-4 walk)
     size_t ws_off[4] = {0, 0, 0, 0}, ws_bytes = 0;
     int ws_tiles[4] = {0, 0, 0, 0}, blocks = 0;
     for (int j = 0; j < n_jobs; ++j) {
@@ -1798,7 +1784,7 @@ extern "C" int lav_gemm_tn_grouped(void* stream, int n_jobs, const lav_gemm_tn_j
     }
     if (ws_bytes) {
         float* ws = splitk_workspace(stream, ws_bytes);
-        LAV_REQUIRE(ws, "lav_gemm_tn_grouped: split-K workspace allocation failed");
+        if (!ws) return LAV_E_WORKSPACE;                     // message set by lav_ws_get
         for (int j = 0; j < n_jobs; ++j)
             if (G.g[j].splits > 1) { G.g[j].ws = (float*)((char*)ws + ws_off[j]); G.g[j].ws_tiles = ws_tiles[j]; }
     }

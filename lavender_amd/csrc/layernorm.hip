@@ -302,68 +302,61 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_many_kernel(LnFinishJobs J)
     }
 }
 
-struct LnDefer { void* stream; float* arena; size_t bytes, used; LnFinishJobs jobs; };
-static LnDefer g_lndefer[4] = {};
-static int g_ln_defer_on = 0;
-#define LN_DEFER_ARENA ((size_t)384 << 20)
+// Per-stream state of the deferred mode: on/off flag, bump offset into the stream's LAV_WS_LN_DEFER workspace, queued jobs.  The table is
+// guarded by a mutex (entry points may be called from several host threads on different streams); a stream's own calls are ordered by
+// the caller, as for any stream.
+#include <mutex>
+struct LnDefer { void* stream; bool used, on; float* arena; size_t bytes, used_bytes; LnFinishJobs jobs; hipEvent_t done; bool has_event; };
+static LnDefer g_lndefer[16] = {};
+static std::mutex g_lndefer_mu;
 
 static LnDefer* ln_defer_state(void* stream, bool create) {
-    for (auto& d : g_lndefer) if (d.arena && d.stream == stream) return &d;
+    std::lock_guard<std::mutex> lk(g_lndefer_mu);
+    for (auto& d : g_lndefer) if (d.used && d.stream == stream) return &d;
     if (!create) return nullptr;
-    for (auto& d : g_lndefer) if (!d.arena) {
-        if (hipMalloc((void**)&d.arena, LN_DEFER_ARENA) != hipSuccess) { (void)hipGetLastError(); d.arena = nullptr; return nullptr; }
-        d.stream = stream; d.bytes = LN_DEFER_ARENA; d.used = 0; d.jobs.n = 0; d.jobs.total_blocks = 0;
+    for (auto& d : g_lndefer) if (!d.used) {
+        d.used = true; d.stream = stream; d.on = false; d.arena = nullptr; d.bytes = 0; d.used_bytes = 0; d.jobs.n = 0; d.jobs.total_blocks = 0; d.has_event = false;
         return &d;
     }
-    return nullptr;                                          // more than 4 streams use the deferred mode: those calls finish at once
+    return nullptr;                                          // more than 16 streams: those calls finish at once
 }
 
 static int ln_defer_flush(LnDefer* d) {
     if (!d || d->jobs.n == 0) return LAV_OK;
     hipLaunchKernelGGL(ln_bwd_finish_many_kernel, dim3(d->jobs.total_blocks, 3), dim3(256), 0, (hipStream_t)d->stream, d->jobs);
-    d->jobs.n = 0; d->jobs.total_blocks = 0; d->used = 0;
+    d->jobs.n = 0; d->jobs.total_blocks = 0; d->used_bytes = 0;
     return lav_check_launch("lav_layernorm_flush");
 }
 
-extern "C" int lav_layernorm_set_defer(int on) { const int old = g_ln_defer_on; g_ln_defer_on = on != 0; return old; }
-
-extern "C" int lav_layernorm_flush(void* stream) { return ln_defer_flush(ln_defer_state(stream, false)); }
-
-// per-stream scratch for the column partials (same pattern as the split-K workspace of gemm.hip: calls on one stream are ordered)
-struct LnWs { void* stream; float* ptr; size_t bytes; };
-static LnWs g_lnws[8] = {};
-static float* ln_workspace(void* stream, size_t bytes) {
-    LnWs* e = nullptr;
-    for (auto& w : g_lnws) if (w.ptr && w.stream == stream) { e = &w; break; }
-    if (!e) for (auto& w : g_lnws) if (!w.ptr) { e = &w; e->stream = stream; break; }
-    if (!e) return nullptr;                                 // more than 8 streams: fall back to the atomics
-    if (bytes > e->bytes) {
-        if (e->ptr) { (void)hipDeviceSynchronize(); (void)hipFree(e->ptr); e->ptr = nullptr; e->bytes = 0; }
-        size_t want = bytes < ((size_t)32 << 20) ? ((size_t)32 << 20) : bytes + bytes / 2;
-        if (hipMalloc((void**)&e->ptr, want) != hipSuccess) { (void)hipGetLastError(); e->ptr = nullptr; return nullptr; }
-        e->bytes = want;
-    }
-    return e->ptr;
+extern "C" int lav_layernorm_set_defer(void* stream, int on) {
+    LnDefer* d = ln_defer_state(stream, true);
+    LAV_REQUIRE(d, "lav_layernorm_set_defer: more than 16 streams use the deferred mode");
+    const int old = d->on ? 1 : 0;
+    if (!on && d->on) { if (int rc = ln_defer_flush(d)) return rc; }
+    d->on = on != 0;
+    return old;
 }
 
-// ring of scratch buffers for the cross-stream column reduction (see lav_layernorm_bwd)
-struct LnRing { float* ptr; size_t bytes; hipEvent_t produced, consumed; bool used, init; };
-static LnRing g_lnring[8] = {};
-static unsigned g_lnring_next = 0;
-static LnRing* ln_ring_slot(size_t bytes) {
-    LnRing* e = &g_lnring[g_lnring_next++ & 7];
-    if (!e->init) {
-        if (hipEventCreateWithFlags(&e->produced, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e->consumed, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        e->init = true;
+// stream != NULL: the queued reductions of that stream, on that stream.  stream == NULL is not accepted here: see lav_layernorm_flush_all.
+extern "C" int lav_layernorm_flush(void* stream) { return ln_defer_flush(ln_defer_state(stream, false)); }
+
+// Every stream's queued reductions, each completed ON ITS OWN stream (behind the row passes that produced the partials); `join_stream`
+// then waits (event, no host synchronisation) for every other stream that had something queued, so work enqueued on join_stream afterwards
+// sees all dgamma / dbeta / colsum vectors complete no matter which stream ran the backward.
+extern "C" int lav_layernorm_flush_all(void* join_stream) {
+    for (auto& d : g_lndefer) {
+        if (!d.used || d.jobs.n == 0) continue;
+        if (int rc = ln_defer_flush(&d)) return rc;
+        if (d.stream != join_stream) {
+            if (!d.has_event) {
+                if (hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); lav_set_error("lav_layernorm_flush_all: event creation failed"); return LAV_E_LAUNCH; }
+                d.has_event = true;
+            }
+            (void)hipEventRecord(d.done, (hipStream_t)d.stream);
+            (void)hipStreamWaitEvent((hipStream_t)join_stream, d.done, 0);
+        }
     }
-    if (bytes > e->bytes) {
-        if (e->ptr) { (void)hipDeviceSynchronize(); (void)hipFree(e->ptr); e->ptr = nullptr; e->bytes = 0; e->used = false; }
-        size_t want = bytes < ((size_t)8 << 20) ? ((size_t)8 << 20) : bytes + bytes / 2;
-        if (hipMalloc((void**)&e->ptr, want) != hipSuccess) { (void)hipGetLastError(); e->ptr = nullptr; return nullptr; }
-        e->bytes = want;
-    }
-    return e;
+    return LAV_OK;
 }
 
 static inline void pick_geom(int C, int& G, int& iters) {
@@ -440,28 +433,22 @@ extern "C" int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, 
     hipStream_t s = (hipStream_t)stream;
     static const bool use_part = !getenv("LAV_LN_ATOMIC_FLUSH");          // test hook: the old per-block atomics
     const bool any_col = dgamma || dbeta || a.ex.colsum;
-    // The column reduction on another stream (lav_ln_bwd_extra.finish_stream): 78 of these 8-us launches sit in the dy -> dx chain
-    // of a pretrain step otherwise.  Partials go to a ring of scratch buffers; a slot is reused only after the finish kernel that
-    // read it has run (the row-pass stream waits for that event -- eight LayerNorm backwards later, so it never actually waits).
-    hipStream_t fs = (hipStream_t)a.ex.finish_stream;
-    LnRing* slot = nullptr;
     LnDefer* defer = nullptr;
     const size_t part_bytes = (size_t)3 * grid * C * sizeof(float);
-    if (use_part && any_col && grid >= 64 && g_ln_defer_on && !(fs && fs != s)) {
-        defer = ln_defer_state(stream, true);
-        if (defer && part_bytes > defer->bytes) defer = nullptr;
-        if (defer && (defer->jobs.n == LN_MAX_JOBS || defer->used + part_bytes > defer->bytes)) { if (int rc = ln_defer_flush(defer)) return rc; }
-        if (defer) { a.part = (float*)((char*)defer->arena + defer->used); defer->used += (part_bytes + 255) & ~(size_t)255; }
-    }
-    if (!defer && use_part && any_col && grid >= 64) {
-        if (fs && fs != s) {
-            slot = ln_ring_slot((size_t)3 * grid * C * sizeof(float));
-            if (slot) {
-                if (slot->used) (void)hipStreamWaitEvent(s, slot->consumed, 0);
-                a.part = slot->ptr;
-            }
+    if (use_part && any_col && grid >= 64) {
+        defer = ln_defer_state(stream, false);
+        if (defer && !defer->on) defer = nullptr;
+        if (defer && !defer->arena) {                        // first deferred call of the stream: its LAV_WS_LN_DEFER workspace (registered or internal)
+            defer->arena = (float*)lav_ws_get(stream, LAV_WS_LN_DEFER, 0, &defer->bytes);
+            if (!defer->arena) return LAV_E_WORKSPACE;
         }
-        if (!a.part) a.part = ln_workspace(stream, (size_t)3 * grid * C * sizeof(float));
+        if (defer && part_bytes > defer->bytes) defer = nullptr;       // a single reduction larger than the arena: finished at once below
+        if (defer && (defer->jobs.n == LN_MAX_JOBS || defer->used_bytes + part_bytes > defer->bytes)) { if (int rc = ln_defer_flush(defer)) return rc; }
+        if (defer) { a.part = (float*)((char*)defer->arena + defer->used_bytes); defer->used_bytes += (part_bytes + 255) & ~(size_t)255; }
+        if (!defer) {
+            a.part = (float*)lav_ws_get(stream, LAV_WS_LN_PARTIALS, part_bytes, nullptr);
+            if (!a.part) return LAV_E_WORKSPACE;
+        }
     }
 #define K_(G_, I_, X_) hipLaunchKernelGGL((ln_bwd_kernel<G_, I_, X_>), dim3(grid), dim3(256), lds, s, a);
     const bool x32 = a.ex.x_f32 == 1;                      // 2 = fp16 rows: the 16-bit instantiation, unpacked as halves (a.ex.x_f32 is read in the kernel)
@@ -472,14 +459,7 @@ extern "C" int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, 
         jb.part = a.part; jb.o0 = dgamma; jb.o1 = dbeta; jb.o2 = a.ex.colsum; jb.nblk = grid; jb.C = C; jb.blk0 = defer->jobs.total_blocks; jb.pad_ = 0;
         defer->jobs.total_blocks += (C + 31) / 32;
     } else if (a.part) {
-        hipStream_t rs = s;
-        if (slot) {
-            (void)hipEventRecord(slot->produced, s);
-            (void)hipStreamWaitEvent(fs, slot->produced, 0);
-            rs = fs;
-        }
-        hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((C + 31) / 32, 3), dim3(256), 0, rs, (const float*)a.part, grid, C, dgamma, dbeta, a.ex.colsum);
-        if (slot) { (void)hipEventRecord(slot->consumed, fs); slot->used = true; }
+        hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((C + 31) / 32, 3), dim3(256), 0, s, (const float*)a.part, grid, C, dgamma, dbeta, a.ex.colsum);
     }
     return lav_check_launch("lav_layernorm_bwd");
 }

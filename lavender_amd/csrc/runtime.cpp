@@ -13,7 +13,7 @@ extern "C" void lav_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* lav_last_error(void) { return g_err; }
-extern "C" int lav_abi_version(void) { return 5; }
+extern "C" int lav_abi_version(void) { return 6; }
 
 // Split-K workspaces, LDS-size attributes, window tables and the optimizer's partial-sum buffer are process-wide (keyed by
 // stream at most): ONE device per process, the deployment model of this library (one rank per GPU).  Every launch checks it,
@@ -35,4 +35,54 @@ int lav_check_launch(const char* what) {
         return LAV_E_LAUNCH;
     }
     return LAV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Scratch workspaces (split-K partial tiles, LayerNorm column partials, the deferred-reduction arena): CALLER-OWNED when the caller
+// registers them (lav_set_workspace), else one internal hipMalloc per (stream, kind) made on first use and never grown, freed or
+// re-made -- a call that needs more than the registered / internal size FAILS with a message naming the size to register; nothing in
+// this library calls hipDeviceSynchronize or hipFree.  The table is guarded by a mutex: entry points may be called from several host
+// threads on different streams.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#include <mutex>
+struct LavWsEntry { void* stream; int kind; void* ptr; size_t bytes; bool used, failed; };
+static LavWsEntry g_ws[64] = {};
+static std::mutex g_ws_mu;
+static const size_t g_ws_default[LAV_WS_KINDS] = {(size_t)256 << 20, (size_t)32 << 20, (size_t)384 << 20};
+static const char* const g_ws_name[LAV_WS_KINDS] = {"LAV_WS_SPLITK", "LAV_WS_LN_PARTIALS", "LAV_WS_LN_DEFER"};
+
+extern "C" size_t lav_workspace_bytes(int kind) { return kind >= 0 && kind < LAV_WS_KINDS ? g_ws_default[kind] : 0; }
+
+extern "C" int lav_set_workspace(void* stream, int kind, void* ptr, size_t bytes) {
+    LAV_REQUIRE(kind >= 0 && kind < LAV_WS_KINDS, "lav_set_workspace: unknown kind %d", kind);
+    LAV_REQUIRE((ptr == nullptr) == (bytes == 0) && ((uintptr_t)ptr & 255) == 0, "lav_set_workspace: a 256-byte aligned buffer and its size, or NULL and 0");
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    LavWsEntry* e = nullptr;
+    for (auto& w : g_ws) if (w.used && w.stream == stream && w.kind == kind) { e = &w; break; }
+    if (!e) for (auto& w : g_ws) if (!w.used) { e = &w; break; }
+    LAV_REQUIRE(e, "lav_set_workspace: more than 64 (stream, kind) workspaces");
+    // (an internal allocation made before this call stays allocated: freeing it would need a device synchronisation)
+    e->used = ptr != nullptr; e->stream = stream; e->kind = kind; e->ptr = ptr; e->bytes = bytes; e->failed = false;
+    return LAV_OK;
+}
+
+void* lav_ws_get(void* stream, int kind, size_t need, size_t* cap) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    LavWsEntry* e = nullptr;
+    for (auto& w : g_ws) if (w.used && w.stream == stream && w.kind == kind) { e = &w; break; }
+    if (!e) {
+        for (auto& w : g_ws) if (!w.used) { e = &w; break; }
+        if (!e) { lav_set_error("workspace table full (64 (stream, kind) pairs)"); return nullptr; }
+        e->used = true; e->stream = stream; e->kind = kind; e->ptr = nullptr; e->failed = false;
+        e->bytes = need > g_ws_default[kind] ? need + need / 2 : g_ws_default[kind];
+        if (hipMalloc(&e->ptr, e->bytes) != hipSuccess) { (void)hipGetLastError(); e->ptr = nullptr; e->failed = true; }   // remembered: not retried per call
+    }
+    if (e->failed || !e->ptr) { lav_set_error("%s: the internal allocation of %zu bytes failed earlier; register a buffer with lav_set_workspace", g_ws_name[kind], e->bytes); return nullptr; }
+    if (need > e->bytes) {
+        lav_set_error("%s on stream %p holds %zu bytes, this call needs %zu: register a larger buffer with lav_set_workspace (workspaces are never re-allocated behind the caller)",
+                      g_ws_name[kind], stream, e->bytes, need);
+        return nullptr;
+    }
+    if (cap) *cap = e->bytes;
+    return e->ptr;
 }

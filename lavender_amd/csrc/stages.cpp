@@ -197,7 +197,7 @@ extern "C" int lav_swin_block_fwd(void* stream, const lav_swin_block_desc* d) {
     LAV_TRY(lav_layernorm_fwd(stream, M, C, d->x_mid, C, nullptr, d->ln2_gamma, d->ln2_beta, d->ln_eps, d->y2, C, d->mean2, d->rstd2, nullptr));
     {
         lav_gemm_epilogue e = epi0();
-        e.bias = d->b_fc1; e.act = 1; e.preact = d->h_pre; e.ldp = 4 * C; e.preact_is_grad = 1;
+        e.bias = d->b_fc1; e.act = 1; e.preact = d->h_pre; e.ldp = 4 * C; e.preact_is_grad = d->h_pre ? 1 : 0;
         LAV_TRY(lav_gemm_bf16(stream, 0, M, 4 * C, C, d->y2, C, d->w_fc1, C, d->h, 4 * C, &e, 1));
     }
     {

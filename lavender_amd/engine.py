@@ -87,6 +87,7 @@ def dw_gemm(A, Bm, M, N, Kd, **kw):
     if not _DW_SIDE:
         return K.gemm(2, A, Bm, M, N, Kd, **kw)
     side = dw_stream(A.device)
+    _arm_join()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         K.gemm(2, A, Bm, M, N, Kd, **kw)
@@ -113,6 +114,7 @@ class DwGroup:
         if not self.jobs:
             return
         side = dw_stream(device)
+        _arm_join()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             K.gemm_tn_grouped(self.jobs, self.gs)
@@ -122,15 +124,31 @@ class DwGroup:
         self.jobs = []
 
 
-_LN_SIDE = os.environ.get("LAV_LN_FINISH_SIDE", "0") != "0"     # measured neutral on the cfg2 step (76.3 vs 76.3-76.6 ms): off by default
-
-
 def ln_bwd(dy, *args, **kw):
-    """K.layernorm_bwd with the column reduction (dgamma / dbeta / bias column sums: parameter gradients) on the weight-gradient
-    stream -- everything that reads those gradients already joins that stream (dw_join, the reducer's range events)."""
-    if _DW_SIDE and _LN_SIDE:
-        kw["finish_stream"] = dw_stream(dy.device)
-    return K.layernorm_bwd(dy, *args, flush=False, **kw)     # deferred column reductions: completed by dw_join / arena events (K.layernorm_flush)
+    """K.layernorm_bwd with the column reductions (dgamma / dbeta / bias column sums: parameter gradients) DEFERRED: completed by dw_join /
+    the arena's range events / the end-of-backward callback (K.layernorm_flush), one launch for all of them."""
+    _arm_join()
+    return K.layernorm_bwd(dy, *args, flush=False, **kw)
+
+
+_join_armed = [False]
+
+
+def _end_of_backward():
+    _join_armed[0] = False
+    dw_join()
+
+
+def _arm_join():
+    """Called by everything that leaves gradient work pending (weight-gradient kernels on the side stream, deferred LayerNorm reductions): the
+    join + flush run once as a final callback of the CURRENT autograd backward pass, so `.grad` is whole when backward() returns -- also for a
+    caller that never heard of dw_join.  Outside a backward pass (kernel-level tests drive these helpers directly) nothing is armed."""
+    if not _join_armed[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+            _join_armed[0] = True
+        except RuntimeError:
+            pass
 
 
 def dw_join(device=None):
@@ -315,7 +333,9 @@ class SwinBlockFn(torch.autograd.Function):
             ctx.keep_attn = float(blk.keep_prob) if dp_attn is not None else 1.0
             ctx.has_dp = dp_attn is not None
             ctx.pad = None
-            ctx.c_stage, ctx.c_fields, ctx.c_consts = True, fields, c
+            # the backward rebuilds the activation addresses from the UNPACKED saved tensors (saved-tensor hooks may move them); kept from
+            # here: the scalar / parameter head of the descriptor and the address of the block output (never read by the backward)
+            ctx.c_stage, ctx.c_head, ctx.c_out, ctx.c_consts = True, fields[:7 + len(c["params"])], out.data_ptr(), c
             ctx.save_for_backward(x, y1, st, qkv, ao, lse, x_mid, y2, h_pre, h,
                                   dp_attn if dp_attn is not None else x.new_empty(0), dp_mlp if dp_mlp is not None else x.new_empty(0))
         return out
@@ -334,9 +354,15 @@ class SwinBlockFn(torch.autograd.Function):
         splits = (K.splits_for(3 * Cn, Cn, M), K.splits_for(Cn, Cn, M, has_dp), K.splits_for(4 * Cn, Cn, M), K.splits_for(Cn, 4 * Cn, M, has_dp))
         b = ctx.c_consts["bwd"]
         gs = K.group_splits_for(((Cn, 4 * Cn), (4 * Cn, Cn), (Cn, Cn), (3 * Cn, Cn)), M)
-        fields = ctx.c_fields + (dy.data_ptr(), alpha, alpha) + b[:21] + splits + (
+        p_st = st.data_ptr()
+        ffields = ctx.c_head + (
+            K._dp(dp_attn if has_dp else None), K._dp(dp_mlp if has_dp else None), x.data_ptr(), y1.data_ptr(), p_st, p_st + 4 * M, qkv.data_ptr(), ao.data_ptr(),
+            lse.data_ptr(), x_mid.data_ptr(), y2.data_ptr(), p_st + 8 * M, p_st + 12 * M, h_pre.data_ptr(), h.data_ptr(), ctx.c_out)
+        fields = ffields + (dy.data_ptr(), alpha, alpha) + b[:21] + splits + (
             dh.data_ptr(), d_y2.data_ptr(), d_mid.data_ptr(), d_ao.data_ptr(), dqkv.data_ptr(), d_y1.data_ptr(), dx.data_ptr(), gs)
         side = dw_stream(dev) if _DW_SIDE else None
+        _arm_join()
+        K.ensure_stage_workspaces(((3 * Cn, Cn), (Cn, Cn), (4 * Cn, Cn), (Cn, 4 * Cn)), splits, gs, side.cuda_stream if side is not None else None)
         K.swin_block_bwd(fields, side.cuda_stream if side is not None else None)
         if side is not None:
             for t in (dy, h, dh, y2, d_mid, ao, dqkv, y1, qkv, d_ao, lse) + ((dp_attn, dp_mlp) if has_dp else ()):
@@ -738,7 +764,8 @@ class BertLayerFn(torch.autograd.Function):
         if keep:
             ctx.layer, ctx.seeds, ctx.p = layer, (s1, s2), p_hidden
             ctx.pair = None
-            ctx.c_fields = fields                              # device addresses stay valid: every buffer is a saved tensor below
+            # the backward rebuilds the activation addresses from the UNPACKED saved tensors (saved-tensor hooks may move them)
+            ctx.c_head, ctx.c_res, ctx.c_y, ctx.c_consts = fields[:12], res, y.data_ptr(), c
             ctx.c_stage = True
             ctx.save_for_backward(x, qkv, cx, lse, pre1, st1, x1, h_pre, h, pre2, st2, key_mask if key_mask is not None else x.new_empty(0),
                                   *(resln_t[:3] if resln_t is not None else ()))
@@ -752,7 +779,7 @@ class BertLayerFn(torch.autograd.Function):
         layer = ctx.layer
         x, qkv, cx, lse, pre1, st1, x1, h_pre, h, pre2, st2 = ctx.saved_tensors[:11]
         R, Hd = cx.shape
-        c = BertLayerFn._layer_consts(layer, layer._arena(), None, None) if layer.__dict__.get("_lav_stage_consts") else None
+        c = ctx.c_consts                                       # the forward's constants (not re-queried: the cache may have been rebuilt since)
         F = c["ffn"]
         dev = x.device
         e = torch.empty
@@ -761,10 +788,19 @@ class BertLayerFn(torch.autograd.Function):
         splits = (K.splits_for(3 * Hd, Hd, R), K.splits_for(Hd, Hd, R), K.splits_for(F, Hd, R), K.splits_for(Hd, F, R))
         b = c["bwd"]
         gs = K.group_splits_for(((Hd, F), (F, Hd), (Hd, Hd), (3 * Hd, Hd)), R)
-        fields = ctx.c_fields + (dy.data_ptr(),) + b[:20] + splits + (
+        saved = ctx.saved_tensors
+        key_mask = saved[11] if saved[11].numel() else None
+        res = ((saved[12].data_ptr(), saved[13].data_ptr(), saved[14].data_ptr()) + ctx.c_res[3:]) if len(saved) > 12 else ctx.c_res
+        p1, p2 = st1.data_ptr(), st2.data_ptr()
+        ffields = ctx.c_head + (K._dp(key_mask),) + c["params"] + (x.data_ptr(),) + res + (
+            qkv.data_ptr(), cx.data_ptr(), lse.data_ptr(), pre1.data_ptr(), p1, p1 + 4 * R, x1.data_ptr(), h_pre.data_ptr(), h.data_ptr(),
+            pre2.data_ptr(), p2, p2 + 4 * R, ctx.c_y, int(STREAM_DT == torch.float16))
+        fields = ffields + (dy.data_ptr(),) + b[:20] + splits + (
             d_pre2.data_ptr(), d_dense2.data_ptr(), dh.data_ptr(), d_x1.data_ptr(), d_pre1.data_ptr(), d_dense1.data_ptr(), d_cx.data_ptr(),
             dqkv.data_ptr(), dx.data_ptr(), gs)
         side = dw_stream(dev) if _DW_SIDE else None
+        _arm_join()
+        K.ensure_stage_workspaces(((3 * Hd, Hd), (Hd, Hd), (F, Hd), (Hd, F)), splits, gs, side.cuda_stream if side is not None else None)
         K.bert_layer_bwd(fields, side.cuda_stream if side is not None else None)
         if side is not None:                                   # operands of the weight-gradient GEMMs: not to be recycled before the side stream ran
             for t in (d_dense2, h, dh, x1, d_dense1, cx, dqkv, x):

@@ -25,6 +25,47 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+# ---- caller-owned scratch (lav_set_workspace): torch allocations registered per (stream, kind) on first need, held for the life of the process.
+WS_SPLITK, WS_LN_PARTIALS, WS_LN_DEFER = 0, 1, 2
+_workspaces = {}
+
+
+def _stream_ptr(stream_ptr=None):
+    if stream_ptr is not None:
+        return int(stream_ptr)
+    if _raw_stream is not None:
+        return int(_raw_stream(torch.cuda.current_device()))
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def ensure_workspace(kind, need=0, stream_ptr=None):
+    """The (stream, kind) workspace exists and holds >= need bytes: lav_workspace_bytes(kind) by default, re-registered larger when a call needs
+    more (the library itself never allocates behind a registered buffer: it fails with LAV_E_WORKSPACE)."""
+    sp = _stream_ptr(stream_ptr)
+    t = _workspaces.get((sp, kind))
+    if t is not None and t.numel() >= need:
+        return
+    size = max(int(L.lib.lav_workspace_bytes(kind)), int(need) + (int(need) // 2 if t is not None else 0))
+    t = torch.empty(size, dtype=torch.uint8, device="cuda")
+    L.check(L.lib.lav_set_workspace(C.c_void_p(sp), kind, C.c_void_p(t.data_ptr()), size), "lav_set_workspace")
+    _workspaces[(sp, kind)] = t           # (a replaced buffer is released to torch's stream-ordered allocator: later kernels of that stream come after its users)
+    if kind == WS_LN_DEFER and LN_DEFER:
+        L.check(L.lib.lav_layernorm_set_defer(C.c_void_p(sp), 1), "lav_layernorm_set_defer")
+
+
+def tn_need(M, N, splits):
+    """upper bound of the split-K workspace bytes of one weight-gradient / split-K GEMM (256 x 256 fp32 partial tiles per split)"""
+    return 0 if splits <= 1 else int(splits) * ((M + 255) // 256) * ((N + 255) // 256) * 262144
+
+
+def ensure_stage_workspaces(shapes, splits, group_splits, side_stream_ptr):
+    """before a stage-level backward entry: LayerNorm scratch on the current stream, split-K partial tiles on the stream that runs the weight gradients"""
+    ensure_workspace(WS_LN_PARTIALS)
+    ensure_workspace(WS_LN_DEFER)
+    need = sum(tn_need(M, N, max(s, group_splits)) for (M, N), s in zip(shapes, splits))
+    ensure_workspace(WS_SPLITK, need, side_stream_ptr)
+
+
 def next_seed():
     """Fresh 32-bit dropout seed (host-side counter hashed; deterministic under torch.manual_seed order)."""
     _seed_counter[0] = (_seed_counter[0] * 1664525 + 1013904223) & 0xFFFFFFFF
@@ -99,6 +140,8 @@ def gemm(layout, A, B, M, N, K, out=None, out_dtype=bf16, bias=None, act=0, prea
                         2 if accumulate else (1 if out.dtype == torch.float32 else (3 if out.dtype == torch.float16 else 0)),
                         _dp(k_keep), int(k_rows_per_group), _dp(rowsum_a), int(preact_is_grad), int(gelu_in_is_grad), int(res32),
                         _dp(a_rowmap), _dp(res_rowmap), ln_m, ln_r, ln_g, ln_b, hm_h, hm_d, hm_rows, int(bool(c_pad_writable)))
+    if splits > 1:
+        ensure_workspace(WS_SPLITK, tn_need(M, N, splits))
     rc = L.lib.lav_gemm_bf16(_s(), layout, M, N, K, A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), out.data_ptr(), ldc, ref, splits)
     if rc != 0:
         L.check(rc, "lav_gemm_bf16")
@@ -115,6 +158,7 @@ def gemm_tn_grouped(jobs, splits):
         q.A, q.lda, q.B, q.ldb, q.C, q.ldc = A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), out.data_ptr(), _ld(out)
         q.rowsum_a, q.k_keep = _dp(j.get("rowsum_a")), _dp(j.get("k_keep"))
         q.k_rows_per_group, q.alpha, q.fallback_splits = int(j.get("k_rows_per_group", 1)), float(j.get("alpha", 1.0)), int(j.get("fallback_splits", 1))
+    ensure_workspace(WS_SPLITK, sum(tn_need(q.M, q.N, max(int(splits), q.fallback_splits)) for q in arr))
     rc = L.lib.lav_gemm_tn_grouped(_s(), len(jobs), arr, int(splits))
     if rc != 0:
         L.check(rc, "lav_gemm_tn_grouped")
@@ -264,33 +308,32 @@ def layernorm_fwd(x, rows, Cn, gamma, beta, eps, gather=None, out=None, want_sta
 
 
 LN_DEFER = _os_env("LAV_LN_DEFER", "1") != "0"      # deferred column reductions of the LayerNorm backward (lav_layernorm_set_defer): one finish launch per flush
-if LN_DEFER:
-    L.lib.lav_layernorm_set_defer(1)
 
 
 def layernorm_flush():
-    """complete the queued column reductions (dgamma / dbeta / colsum) of the current stream: lav_layernorm_flush"""
+    """complete the queued column reductions (dgamma / dbeta / colsum) of EVERY stream (each on its own stream) and make the current stream
+    wait for them: lav_layernorm_flush_all.  Whatever stream ran the backward, work enqueued on the current stream afterwards sees them."""
     if LN_DEFER:
-        rc = L.lib.lav_layernorm_flush(_s())
+        rc = L.lib.lav_layernorm_flush_all(_s())
         if rc != 0:
-            L.check(rc, "lav_layernorm_flush")
+            L.check(rc, "lav_layernorm_flush_all")
 
 
 def layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dgamma, dbeta, gather=None, add_in=None, dx=None, dx2=None,
-                  row_scale=None, rows_per_group=1, dropout_p=0.0, seed=0, colsum=None, finish_stream=None, flush=True):
-    """finish_stream (a torch.cuda.Stream): dgamma / dbeta / colsum are completed there (lav_ln_bwd_extra.finish_stream); the
-    caller joins it before reading them.  flush=False (the engine): in the deferred mode the three vectors are only complete after
-    layernorm_flush() on this stream; the default completes them before returning, as without the mode."""
+                  row_scale=None, rows_per_group=1, dropout_p=0.0, seed=0, colsum=None, flush=True):
+    """flush=False (the engine): in the deferred mode dgamma / dbeta / colsum are only complete after layernorm_flush(); the default
+    completes them before returning, as without the mode."""
     dev = dy.device
+    ensure_workspace(WS_LN_PARTIALS)
+    ensure_workspace(WS_LN_DEFER)
     if dx is None:
         dx = torch.empty((rows * 4, Cn // 4) if gather is not None else (rows, Cn), dtype=bf16, device=dev)
     ldx = gather[2] if gather is not None else _ld(x)
     lddx = gather[2] if gather is not None else _ld(dx)
     ex = None
     x32 = 1 if x.dtype == torch.float32 else (2 if x.dtype == torch.float16 else 0)      # lav_ln_bwd_extra.x_f32
-    if dx2 is not None or colsum is not None or x32 or finish_stream is not None:
+    if dx2 is not None or colsum is not None or x32:
         s = L.LnBwdExtra()
-        s.finish_stream = finish_stream.cuda_stream if finish_stream is not None else None
         s.x_f32 = int(x32)
         s.dx2 = _p(dx2)
         s.lddx2 = _ld(dx2) if dx2 is not None else 0

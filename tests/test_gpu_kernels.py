@@ -536,32 +536,106 @@ def test_gemm_reads_a_and_residual_through_a_row_map():
     close(y0, ref, atol=3e-2, rtol=2e-2, what="gathered GEMM vs fp32 reference")
 
 
-def test_layernorm_backward_column_reduction_on_another_stream():
-    """lav_ln_bwd_extra.finish_stream: dgamma / dbeta / colsum completed on a second stream give the same values; the ring of
-    scratch buffers survives more calls than it has slots."""
-    rows, Cn = 45120 // 8, 768
+def test_layernorm_deferred_reductions_of_another_stream_are_completed_by_flush_all():
+    """The backward runs on stream A (deferred column reductions queued THERE), the reader calls layernorm_flush() on stream B: every queue is
+    completed on its own stream and B waits for it (lav_layernorm_flush_all) -- the gradients are whole, bit-identical to the immediate mode."""
+    from lavender_amd import hip as KK
+    if not KK.LN_DEFER:
+        pytest.skip("LAV_LN_DEFER=0")
+    rows, Cn = 45120 // 4, 768
     x, dy = rb(rows, Cn, seed=1), rb(rows, Cn, seed=2)
     gamma = torch.randn(Cn, device="cuda")
-    mean = x.float().mean(-1); rstd = (x.float().var(-1, unbiased=False) + 1e-5).rsqrt()
-    side = torch.cuda.Stream()
-    ref = None
-    for it in range(11):
-        dg, db = torch.zeros(Cn, device="cuda"), torch.zeros(Cn, device="cuda")
-        cs = torch.zeros(Cn, device="cuda")
+    _, mean, rstd = KK.layernorm_fwd(x, rows, Cn, gamma, torch.zeros(Cn, device="cuda"), 1e-5)
+    outs = []
+    for deferred_on_side in (False, True):
+        dg, db, cs = (torch.zeros(Cn, device="cuda") for _ in range(3))
         dx2 = torch.empty_like(x)
-        fs = side if it else None
-        side.wait_stream(torch.cuda.current_stream())             # the zero-filled outputs above
-        dx = K().layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dg, db, dx2=dx2, dropout_p=0.1, seed=5, colsum=cs, finish_stream=fs)
-        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        cur = (dx.clone(), dg.clone(), db.clone(), cs.clone())
-        if ref is None:
-            ref = cur
-            assert float(dg.abs().sum()) > 0 and float(cs.abs().sum()) > 0
+        if deferred_on_side:
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                dx = KK.layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dg, db, dx2=dx2, dropout_p=0.1, seed=5, colsum=cs, flush=False)
+            KK.layernorm_flush()                                   # on the default stream: must also complete what `side` queued
+            snap = (dg.clone(), db.clone(), cs.clone())            # enqueued on the default stream, behind the flush's event wait
+            torch.cuda.synchronize()
+            outs.append((dx,) + snap)
         else:
-            assert torch.equal(cur[0], ref[0])
-            for a_, b_ in zip(cur[1:], ref[1:]):
-                assert torch.allclose(a_, b_, rtol=1e-5, atol=1e-4)    # atomics: summation order of the 24 column blocks
+            dx = KK.layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dg, db, dx2=dx2, dropout_p=0.1, seed=5, colsum=cs)
+            torch.cuda.synchronize()
+            outs.append((dx, dg, db, cs))
+    assert float(outs[0][1].abs().sum()) > 0 and float(outs[0][3].abs().sum()) > 0
+    for u, v, what in zip(outs[0], outs[1], ("dx", "dgamma", "dbeta", "colsum")):
+        assert torch.equal(u, v), f"{what}: the queue of the other stream was not completed"
+
+
+def test_two_host_threads_on_two_streams_split_k_gemm_and_deferred_layernorm():
+    """The library's mutable state is per stream and mutex-guarded (include/lavender_hip.h conventions): two host threads, each on its own
+    stream with its own registered workspaces, run split-K weight-gradient GEMMs and deferred LayerNorm backwards concurrently; every result
+    is bit-equal to the same calls made serially on one stream."""
+    import threading
+    from lavender_amd import hip as KK
+    M, N, Kd, rows, Cn = 768, 768, 8192, 6144, 768
+    A, Bm = rb(Kd, M, seed=3), rb(Kd, N, seed=4)
+    x, dy = rb(rows, Cn, seed=5), rb(rows, Cn, seed=6)
+    gamma = torch.randn(Cn, device="cuda")
+    _, mean, rstd = KK.layernorm_fwd(x, rows, Cn, gamma, torch.zeros(Cn, device="cuda"), 1e-5)
+    torch.cuda.synchronize()
+
+    def work(reps):
+        res = []
+        for _ in range(reps):
+            dW = torch.zeros(M, N, device="cuda")
+            KK.gemm(2, A, Bm, M, N, Kd, out=dW, accumulate=True, splits=8)
+            dg, db, cs = (torch.zeros(Cn, device="cuda") for _ in range(3))
+            dx = KK.layernorm_bwd(dy, x, rows, Cn, gamma, mean, rstd, dg, db, colsum=cs, dx2=torch.empty_like(x), flush=False)
+            res.append((dW, dg, db, cs, dx))
+        KK.layernorm_flush()
+        torch.cuda.current_stream().synchronize()
+        return res
+
+    serial = work(6)
+    out, err = {}, []
+
+    def runner(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out[i] = work(6)
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    ts = [threading.Thread(target=runner, args=(i,)) for i in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not err, err
+    torch.cuda.synchronize()
+    for i in range(2):
+        for r, (got, want) in enumerate(zip(out[i], serial)):
+            for u, v, what in zip(got, want, ("dW", "dgamma", "dbeta", "colsum", "dx")):
+                assert torch.equal(u, v), f"thread {i}, repetition {r}: {what} differs from the serial run"
+
+
+def test_a_registered_workspace_is_never_outgrown_behind_the_caller():
+    """lav_set_workspace: a call that needs more than the registered size fails with LAV_E_WORKSPACE and names the size; nothing is allocated,
+    synchronised or freed behind the caller.  Registering a larger buffer makes the same call succeed."""
+    import ctypes as C
+    from lavender_amd import hip as KK, _lib as L
+    M, N, Kd = 768, 768, 4096
+    A, Bm = rb(Kd, M, seed=3), rb(Kd, N, seed=4)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        sp = st.cuda_stream
+        small = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+        L.check(L.lib.lav_set_workspace(C.c_void_p(sp), KK.WS_SPLITK, C.c_void_p(small.data_ptr()), small.numel()))
+        KK._workspaces[(sp, KK.WS_SPLITK)] = torch.empty(1 << 30, dtype=torch.uint8, device="meta")     # keep ensure_workspace out of the way
+        dW = torch.zeros(M, N, device="cuda")
+        with pytest.raises(L.LavenderHipError, match="LAV_WS_SPLITK.*register a larger buffer"):
+            KK.gemm(2, A, Bm, M, N, Kd, out=dW, accumulate=True, splits=8)
+        del KK._workspaces[(sp, KK.WS_SPLITK)]
+        KK.gemm(2, A, Bm, M, N, Kd, out=dW, accumulate=True, splits=8)     # ensure_workspace registers lav_workspace_bytes(kind)
+        st.synchronize()
+    ref = A.float().t() @ Bm.float()
+    close(dW, ref, atol=0.5, rtol=2e-2, what="split-K weight gradient through a caller-owned workspace")
+    assert int(L.lib.lav_workspace_bytes(KK.WS_SPLITK)) == 256 << 20
 
 
 # ---------------------------------------------------------------------------------------------- attention

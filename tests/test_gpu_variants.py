@@ -564,3 +564,55 @@ def test_stage_level_c_entries_match_the_per_kernel_path(size):
         assert ((got_all - ref_all).norm() / ref_all.norm()).item() < 1e-5
     finally:
         E.STAGE_C, K._TN_GROUP = keep, keep_group
+
+
+def test_gradients_are_whole_when_backward_returns_and_saved_tensors_may_move():
+    """(advisor, round 4)  (1) Nothing but `loss.backward()`: the weight-gradient kernels of the side stream and the deferred LayerNorm column
+    reductions are joined / flushed by a final callback of the backward pass itself (engine._arm_join), so gradients read on the current stream
+    right after backward() -- no dw_join, no synchronize -- are complete.  (2) Under saved-tensor hooks that MOVE every saved activation (clone on
+    pack: the forward's own buffers are freed and recycled before the backward runs) the stage-level C entries take the activation addresses
+    from the unpacked tensors, not from the forward's descriptor: same gradients."""
+    from tests.helpers import Tok, make_args
+    import lavender_amd as LA
+    from lavender_amd import hip as K
+    from lavender_amd.dist import set_seed
+    B = 4
+    set_seed(88)
+    args = make_args("micro", "b2l", B)                          # hidden 768: fusion layers and Swin blocks go through the stage-level entries
+    vocab = BERT_CFGS["b2l"]["vocab"]
+    m = LA.LAVENDER_Pretrain_MLM(args, Tok()).cuda()
+    ar = m.arena()
+    ag = LA.Agent_Pretrain_MLM(args, m)
+    b = make_batch(B, vocab=vocab)
+    torch.manual_seed(5)
+    b.update(ag.masking(b["txt"], b["mask"]))
+    batch = ag.prepare_batch(b)
+
+    def run(hooked, join):
+        import contextlib
+        K.reseed(4321)
+        np.random.seed(3)
+        m.train()
+        ar.zero_grad()
+        ctx = torch.autograd.graph.saved_tensors_hooks(lambda t: t.clone() if t.is_cuda and t.numel() else t, lambda t: t) if hooked else contextlib.nullcontext()
+        with ctx:
+            out = m(batch)
+            ls = (ag.loss_func(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten(), batch["_n_mtm"]) +
+                  ag.loss_func(out["out_vtm"].flatten(0, 1), out["ans_vtm"].flatten(), B * 4))
+        junk = [torch.full((1 << 22,), 7.0, device="cuda") for _ in range(8)]      # recycle what the hooks freed
+        ls.backward()
+        if join:
+            import lavender_amd.engine as E
+            E.dw_join()
+            torch.cuda.synchronize()
+        g = ar.grad.clone()                                      # current stream, straight behind backward()
+        torch.cuda.synchronize()
+        del junk
+        return g
+
+    ref = run(False, True)
+    assert float(ref.abs().sum()) > 0
+    for hooked in (False, True):
+        g = run(hooked, False)
+        rel = ((g - ref).norm() / ref.norm()).item()
+        assert rel < 1e-5, (hooked, rel)                         # (vectors accumulated with atomics differ in their last bits)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(_lib.lib, name), f"{name} declared in lavender_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.lib.lav_abi_version() == 5
+    assert _lib.lib.lav_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_argument_errors_are_reported_not_thrown():
