@@ -94,8 +94,18 @@ def train_on_tsv(args, txt_data, tokzr):
                     print(f"Ep {e + 1}, dataset {d}, part {part}: {json.dumps(ls_tr)}, {json.dumps(ac_vl)}")
 
 
+def name_the_run(args):
+    """main_pretrain_mlm.py:239-244 / main_pretrain_task_specific.py: the task carries the dataset names and every run writes into its own
+    `<path_output>/_<task>_<YYYYmmddHHMMSS>` directory (args.json, the checkpoints)."""
+    from datetime import datetime
+    for d in args.dataset:
+        args.task += f"-{d}"
+    args.path_output = '%s/_%s_%s' % (args.path_output, args.task, datetime.now().strftime('%Y%m%d%H%M%S'))
+
+
 if __name__ == '__main__':
     args = get_args()
+    name_the_run(args)
     real = real_data(args)
     if real is not None:
         train_on_tsv(args, *real)

@@ -29,8 +29,18 @@ class SyntheticPretrainTS(SyntheticPretrain):
         return {"img": img, "txt": txt, "mask": (txt != 0).long()}
 
 
+def name_the_run(args):
+    """main_pretrain_mlm.py:239-244 / main_pretrain_task_specific.py: the task carries the dataset names and every run writes into its own
+    `<path_output>/_<task>_<YYYYmmddHHMMSS>` directory (args.json, the checkpoints)."""
+    from datetime import datetime
+    for d in args.dataset:
+        args.task += f"-{d}"
+    args.path_output = '%s/_%s_%s' % (args.path_output, args.task, datetime.now().strftime('%Y%m%d%H%M%S'))
+
+
 if __name__ == '__main__':
     args = get_args()
+    name_the_run(args)
     tokzr = _Tok()
     n_steps = int(os.environ.get("LAV_SYNTH_STEPS", 20))
     ds = SyntheticPretrainTS(args, n_steps * args.size_batch * get_world_size())

@@ -7,6 +7,8 @@ which is what PyTorch's own bf16 autocast of the reference achieves (BASELINE.md
 (labels, pairing) are bit-exact."""
 import os
 
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -257,6 +259,13 @@ def test_base_12l_forward_at_the_benchmark_batch_vs_oracle():
         print(key, tuple(a.shape), "max", d.max().item(), "mean", d.mean().item(), "argmax agree", agree, "margin at disagreements", margin,
               "logit rms", b.pow(2).mean().sqrt().item())
         assert d.max() < 3e-2 and d.mean() < 5e-3 and agree >= 0.95 and margin < 2 * d.max().item() and margin < 3e-2
+        # The error BUDGET (tests/bf16_error_budget.py -> tests/golden/bf16_error_budget.json): the oracle with the product path's roundings
+        # injected and otherwise exact arithmetic predicts the mean |d logit|; the production kernels may exceed it by 30 % (fp32 summation
+        # order, exp2 soft-max, hardware packs: measured 18 %) -- a kernel bug that doubles the error while staying under the T3 bounds
+        # above does not pass any more.
+        budget = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_error_budget.json")))["variants"]["shipped"]
+        print(key, "mean / predicted", d.mean().item() / budget["mean"], "max / predicted", d.max().item() / budget["max"])
+        assert d.mean().item() <= 1.3 * budget["mean"], (key, d.mean().item(), budget["mean"])
         del a, b, d
     print("loss", ls_mtm.item(), ls_vtm.item(), "oracle", l1.item(), l2.item())
     assert abs(ls_mtm.item() - l1.item()) < 1e-2 and abs(ls_vtm.item() - l2.item()) < 1e-2
