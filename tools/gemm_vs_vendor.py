@@ -48,9 +48,14 @@ shapes = {}
 orig = K.gemm
 
 
+padw = set()                                       # shapes the step launches with c_pad_writable (ragged N, padding columns of the output writable)
+
+
 def rec(layout, A, Bm, M, N, Kd, **kw):
     key = (layout, M, N, Kd, kw.get("splits", 1))
     shapes[key] = shapes.get(key, 0) + 1
+    if kw.get("c_pad_writable"):
+        padw.add(key)
     return orig(layout, A, Bm, M, N, Kd, **kw)
 
 
@@ -89,7 +94,7 @@ for (layout, M, N, Kd, sp), calls in sorted(shapes.items(), key=lambda kv: -kv[1
         ven = lambda: torch.matmul(A.t(), Bm)
     else:
         Cb = torch.empty((M, (N + 7) // 8 * 8), dtype=bf, device="cuda")[:, :N]
-        lav = lambda: orig(layout, A, Bm, M, N, Kd, out=Cb, splits=sp)
+        lav = lambda: orig(layout, A, Bm, M, N, Kd, out=Cb, splits=sp, c_pad_writable=(layout, M, N, Kd, sp) in padw)   # as the step launches it
         ven = (lambda: torch.matmul(A, Bm.t())) if layout == 0 else (lambda: torch.matmul(A, Bm))
     tl, tv = [], []
     for _ in range(ROUNDS):
