@@ -114,7 +114,11 @@ __global__ __launch_bounds__(256, 2) void seq_fwd3(AttnArgs a, int nprob) {
         sdma_wait_all();
         __syncthreads();
 
-        for (int qt = wave; qt < nt; qt += 4) {
+        // One query tile: key tiles t0, t0 + tstep, ...  split = false: all of them, normalise and store.  split = true (the LAST query tile when
+        // nt = 4 k + 1, e.g. the 9 tiles of a 282-token sequence): this wave took every fourth key tile; the four partial (m, l, O) states are
+        // merged through LDS (the K / V images are dead by then).  Without the split the wave that owns tile 8 runs 27 (query, key) tile pairs
+        // against 18 of the other three -- the workgroup waits for it; with it the loads are 21 / 20 / 20 / 20.
+        auto run_q = [&](const int qt, const int t0, const int tstep, const bool split) {
             const int q = qt * 32 + j;
             const bool q_ok = q < N;
             const long qrow = (long)min(q, N - 1);
@@ -183,17 +187,61 @@ __global__ __launch_bounds__(256, 2) void seq_fwd3(AttnArgs a, int nprob) {
                     o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_k64(Vs, t * 32 + 16 * sl, 32, lane), pq.b, o1, 0, 0, 0);
                 }
             };
-            qk(0, sa);
+            if (t0 < nt) qk(t0, sa);
 #pragma unroll 1
-            for (int t = 0; t < nt; t += 2) {
-                if (t + 1 < nt) qk(t + 1, sb);
+            for (int t = t0; t < nt; t += 2 * tstep) {
+                if (t + tstep < nt) qk(t + tstep, sb);
                 soft(t, sa);
-                if (t + 1 < nt) {
-                    if (t + 2 < nt) qk(t + 2, sa);
-                    soft(t + 1, sb);
+                if (t + tstep < nt) {
+                    if (t + 2 * tstep < nt) qk(t + 2 * tstep, sa);
+                    soft(t + tstep, sb);
                 }
             }
-            const float l_tot = lower_half(lacc[0]);
+            float l_tot = lower_half(lacc[0]);
+            if (split) {
+                __syncthreads();                             // every wave is done with the K / V images: their space takes the partial states
+                float* part = (float*)smem + wave * 2048;    // [8][64 lanes][4] accumulator quads of this wave
+                float* ml = (float*)smem + 4 * 2048;         // [4 waves][2][32]
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    *(float4*)(part + (r4 * 64 + lane) * 4) = make_float4(o0[4 * r4], o0[4 * r4 + 1], o0[4 * r4 + 2], o0[4 * r4 + 3]);
+                    *(float4*)(part + ((4 + r4) * 64 + lane) * 4) = make_float4(o1[4 * r4], o1[4 * r4 + 1], o1[4 * r4 + 2], o1[4 * r4 + 3]);
+                }
+                if (hi == 0) { ml[wave * 64 + j] = m_run; ml[wave * 64 + 32 + j] = l_tot; }
+                __syncthreads();
+                float m_all = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) m_all = fmaxf(m_all, ml[w * 64 + j]);
+                float sw[4];
+                l_tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float mw = ml[w * 64 + j];
+                    sw[w] = mw == -INFINITY ? 0.f : fast_exp2(mw - m_all);
+                    l_tot = fmaf(sw[w], ml[w * 64 + 32 + j], l_tot);
+                }
+                m_run = m_all;
+                // this wave finishes accumulator quad `wave` of both halves: rows d = 8 wave + 4 hi .. + 3 (and + 32)
+                float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float4 u = *(const float4*)((const float*)smem + w * 2048 + (wave * 64 + lane) * 4);
+                    const float4 v = *(const float4*)((const float*)smem + w * 2048 + ((4 + wave) * 64 + lane) * 4);
+                    a0[0] = fmaf(sw[w], u.x, a0[0]); a0[1] = fmaf(sw[w], u.y, a0[1]); a0[2] = fmaf(sw[w], u.z, a0[2]); a0[3] = fmaf(sw[w], u.w, a0[3]);
+                    a1[0] = fmaf(sw[w], v.x, a1[0]); a1[1] = fmaf(sw[w], v.y, a1[1]); a1[2] = fmaf(sw[w], v.z, a1[2]); a1[3] = fmaf(sw[w], v.w, a1[3]);
+                }
+                const float inv_ls = l_tot > 0.f ? 1.f / l_tot : 0.f;
+                if (q_ok) {
+                    bf16_t* op = a.o_w + ((long)prob * N + q) * C + head * HD;
+                    uint2 w2;
+                    w2.x = pack2(a0[0] * inv_ls, a0[1] * inv_ls); w2.y = pack2(a0[2] * inv_ls, a0[3] * inv_ls);
+                    *(uint2*)(op + 8 * wave + 4 * hi) = w2;
+                    w2.x = pack2(a1[0] * inv_ls, a1[1] * inv_ls); w2.y = pack2(a1[2] * inv_ls, a1[3] * inv_ls);
+                    *(uint2*)(op + 32 + 8 * wave + 4 * hi) = w2;
+                    if (a.lse && hi == 0 && wave == 0) a.lse[(long)p * a.Npad + q] = m_run + log2f(l_tot);
+                }
+                return;
+            }
             const float inv_l = l_tot > 0.f ? 1.f / l_tot : 0.f;
             if (q_ok) {
                 bf16_t* op = a.o_w + ((long)prob * N + q) * C + head * HD;
@@ -209,7 +257,11 @@ __global__ __launch_bounds__(256, 2) void seq_fwd3(AttnArgs a, int nprob) {
                 }
                 if (a.lse && hi == 0) a.lse[(long)p * a.Npad + q] = m_run + log2f(l_tot);   // log2 domain
             }
-        }
+        };
+        const bool split_last = (nt & 3) == 1 && nt >= 5;
+        const int nwhole = split_last ? nt - 1 : nt;
+        for (int qt = wave; qt < nwhole; qt += 4) run_q(qt, 0, 1, false);
+        if (split_last) run_q(nt - 1, wave, 4, true);
     }
 }
 
