@@ -507,7 +507,10 @@ int lav_swin_block_bwd(void* stream, void* side_stream, const lav_swin_block_bwd
  *   LAV_LN_ATOMIC_FLUSH (LayerNorm backward column sums by per-block atomics), LAV_WIN_BWD1 (0: window attention backward as the two
  *   round-3 passes instead of the one-pass kernel), LAV_WINL / LAV_SEQL (0: large windows / long sequences on the generic kernels).
  * lav_gemm_select(which, value) changes the GEMM ones of these at run time (same caveat: process-wide, for probes).
+ * lav_probe_win_prof(buf): NULL = off; else the next stage-2-sized window backward runs the s_memtime-stamped build of win_bwd1 and
+ * writes 160 uint64 stamps to the device buffer `buf` (tools/win_prof.py; profiles/r05_win_bwd1.md).
  * --------------------------------------------------------------------------------------------- */
+void lav_probe_win_prof(void* buf);
 
 #ifdef __cplusplus
 }

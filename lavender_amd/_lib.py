@@ -98,6 +98,7 @@ _SIGS = {
     "lav_abi_version": (i32, []),
     "lav_gemm_bf16": (i32, [vp, i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, P(GemmEpilogue), i32]),
     "lav_gemm_select": (i32, [i32, i32]),
+    "lav_probe_win_prof": (None, [vp]),
     "lav_gemm_tn_grouped": (i32, [vp, i32, P(GemmTnJob), i32]),
     "lav_bert_layer_fwd": (i32, [vp, P(BertLayerDesc)]),
     "lav_bert_layer_bwd": (i32, [vp, vp, P(BertLayerBwdDesc)]),

@@ -18,7 +18,6 @@ att.fwd(qkv, out, lse)
 for _ in range(3):
     att.bwd(qkv, out, dout, lse, dqkv, None)
 prof = torch.zeros(2 * 8 * 8 + 32, dtype=torch.int64, device="cuda")
-L.lib.lav_probe_win_prof.argtypes = [C.c_void_p]
 L.lib.lav_probe_win_prof(prof.data_ptr())
 att.bwd(qkv, out, dout, lse, dqkv, None)
 torch.cuda.synchronize()
