@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lavender_amd import hip as K
-n, L, heads, p = 128, 282, 12, 0.1
+n, L, heads, p = 160, 282, 12, 0.1          # the cfg2 step: 32 MTM + 128 VTM sequences
 Hd = heads * 64
 qkv = torch.randn(n * L, 3 * Hd, device="cuda").bfloat16()
 km = torch.ones(n, L, dtype=torch.int32, device="cuda")
