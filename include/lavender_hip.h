@@ -198,7 +198,8 @@ int lav_layernorm_bwd(void* stream, int rows, int C, const void* dy, long lddy, 
  * vectors are parameter gradients (nn.LayerNorm weight / bias, the bias of the dense layer in front): nothing in the dy -> dx chain reads
  * them, so the caller flushes where gradients become final (before the gradient exchange, the norm, the optimizer).  A call flushes by
  * itself when 48 reductions are queued or the arena is full; switching the mode off flushes.  set_defer returns the previous mode (0 / 1)
- * or an error code.  Default: off. */
+ * or an error code.  Default: off.  lav_layernorm_flush_all touches every stream's queue: call it when no other host thread is inside a
+ * LayerNorm backward (the usual place -- after the backward pass -- is such a point). */
 int lav_layernorm_set_defer(void* stream, int on);
 int lav_layernorm_flush(void* stream);
 int lav_layernorm_flush_all(void* join_stream);
