@@ -6,6 +6,10 @@ this module raises.  Build it with ``python -c "import __graft_entry__ as g; g.b
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- BEFORE the CDLL below: the streams and device memory this library is handed come from torch's copy of the
+#                              HIP runtime; loaded first, that copy is the libamdhip64 our .so binds to (loaded after ours, the process holds two
+#                              runtimes and the first launch fails with "no ROCm-capable device is detected": __graft_entry__.build() + smoke())
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblavender_hip.so")
 
