@@ -322,3 +322,119 @@ def test_keep_logits_flag_leaves_the_outputs_intact_and_the_gradients_equal():
         res.append((ls.item(), m.arena().grad.clone()))
     rel = ((res[0][1] - res[1][1]).norm() / res[0][1].norm()).item()       # atomics make two runs differ in the last bits
     assert abs(res[0][0] - res[1][0]) < 1e-4 and rel < 1e-4, (res[0][0], res[1][0], rel)
+
+
+def test_base_12l_backward_at_the_benchmark_batch_cut_graph_vs_oracle():
+    """A BACKWARD check at the shape bench.py times (B = 32: 160 fusion sequences of 282 tokens, M = 45120 GEMMs with the step's tile / split-K /
+    grouped weight-gradient choices, 1920-problem attention backward, 5120 x 30522 cross-entropy).  The whole model's oracle backward at this batch
+    needs ~5 GB of fp32 autograd state per sample on the host, so the graph is CUT: the GPU runs the full eval-mode forward + backward; the input of the
+    LAST fusion layer is captured on the way (its saved pre-LayerNorm rows, normalised on the host in fp32) and the oracle runs that layer + the MLM head +
+    both losses + their backward from it.  Every parameter gradient downstream of the cut -- the layer's four projections, LayerNorms, the head's
+    transform and the tied 30522-wide decoder -- is compared tensor by tensor (tier T3: relative L2 <= 4 %, cosine >= 0.995).  Second cut, same run: a
+    SHIFTED Swin stage-2 block (2048 window problems per launch: the one-pass window backward, the bias-table gradient on the side stream, the
+    M = 31360 GEMMs) -- its captured input and the gradient that reached its output go through the oracle block as a vector-Jacobian product, and
+    all 13 parameter gradients of the block incl. relative_position_bias_table are compared."""
+    from tests.helpers import build_filled_model
+    from lavender_amd.agent import CrossEntropyIgnore
+    import lavender_amd.engine as E
+    R, P, batch, bc = _oracle_case("base", "b12l", 32)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    m = build_filled_model("base", "b12l", 32).eval()
+    ar = m.arena()
+    last = m.trsfr.layer[-1]
+    seen = {}
+    orig_apply = E.BertLayerFn.apply
+
+    def spy(anchor, x, x32, lyr, km, n, L, *rest):
+        if lyr is last:
+            seen.update(x32=x32, km=km, n=n, L=L)
+        return orig_apply(anchor, x, x32, lyr, km, n, L, *rest)
+
+    # a shifted stage-2 Swin block (2048 window problems per launch at this batch): its input and the gradient arriving at its output are
+    # captured, the oracle block runs forward from that input and backward from that gradient (a vector-Jacobian check inside the real step)
+    blk = m.enc_img.swin.layers[2].blocks[1]
+    assert any(blk.shift_size)
+    sw = {}
+    orig_swin = E.SwinBlockFn.apply
+
+    def spy_swin(anchor, x, b_, geo, dpa, dpm):
+        y = orig_swin(anchor, x, b_, geo, dpa, dpm)
+        if b_ is blk:
+            sw.update(x=x.detach().clone(), geo={k: geo[k] for k in ("B", "D", "H", "W", "cfg_window")})
+            y.register_hook(lambda g: sw.__setitem__("dy", g.detach().clone()))
+        return y
+
+    E.SwinBlockFn.apply = spy_swin
+    E.BertLayerFn.apply = spy
+    try:
+        ar.zero_grad()
+        np.random.seed(88)
+        out = m(_to_cuda(batch))
+        lf = CrossEntropyIgnore()
+        ls = lf(out["out_mtm"].flatten(0, 1), out["ans_mtm"].flatten()) + lf(out["out_vtm"].flatten(0, 1), out["ans_vtm"].flatten())
+        ls.backward()
+        E.dw_join()
+        torch.cuda.synchronize()
+    finally:
+        E.BertLayerFn.apply = orig_apply
+        E.SwinBlockFn.apply = orig_swin
+    assert seen and seen["x32"] is not None, "the last fusion layer was not reached through the recomputed-LayerNorm residual path"
+    pre, mean, rstd, gamma, beta = (t.float().cpu() for t in seen["x32"])
+    n, L, Hd = seen["n"], seen["L"], pre.shape[1]
+    assert (n, L) == (160, 282)
+    x_in = (((pre - mean[:, None]) * rstd[:, None]) * gamma + beta).view(n, L, Hd)
+    km = seen["km"].cpu().long()
+    names = [k for k in P if k.startswith(f"trsfr.layer.{len(m.trsfr.layer) - 1}.") or k.startswith("fc_mtm.")]
+    for k in names:
+        P[k].requires_grad_(True)
+    X = batch["txt"].shape[1]
+    Lv = L - X
+    hid = R.bert_layer(P, f"trsfr.layer.{len(m.trsfr.layer) - 1}", x_in, R.extended_mask(km), bc["heads"])
+    logits = R.mlm_head(P, hid[:, Lv:])
+    ref = dict(out_mtm=logits[:32], out_vtm=logits[32:], ans_mtm=batch["ans_mtm"], ans_vtm=out["ans_vtm"].cpu())
+    l1, l2 = R.pretrain_loss(ref)
+    (l1 + l2).backward()
+    assert abs((l1 + l2).item() - ls.item()) < 2e-2
+    worst, bad, checked = (None, 0.0), [], 0
+    for name, p in m.named_parameters():                     # (decoder.bias is the SAME tensor as predictions.bias on both sides: one gradient)
+        if name not in names or P[name].grad is None:
+            continue
+        a, b = p.grad.float().cpu(), P[name].grad
+        if b.norm() < 1e-7:                                  # the key bias: soft-max is shift-invariant, its true gradient is 0
+            assert a.norm() < 1e-3, (name, a.norm().item())
+            continue
+        rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+        cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+        checked += 1
+        if rel > worst[1]:
+            worst = (name, rel)
+        if not (rel < 0.04 and cos > 0.995):
+            bad.append((name, round(rel, 4), round(cos, 5)))
+    print("tensors checked", checked, "worst relative gradient error", worst, "out of tolerance", bad)
+    assert checked >= 18 and not bad, bad
+    # ---- the Swin block: oracle VJP from the captured input / output gradient
+    g = sw["geo"]
+    pre_b = "enc_img.swin.layers.2.blocks.1"
+    bn = [k for k in P if k.startswith(pre_b + ".")]
+    assert f"{pre_b}.attn.relative_position_bias_table" in bn
+    for k in bn:
+        P[k].requires_grad_(True)
+        P[k].grad = None
+    Cb = sw["x"].shape[1]
+    xb = sw["x"].float().cpu().view(g["B"], g["D"], g["H"], g["W"], Cb).requires_grad_(True)
+    yb = R.swin_block(P, pre_b, xb, blk.num_heads, tuple(g["cfg_window"]), tuple(blk.shift_size))
+    yb.backward(sw["dy"].float().cpu().view_as(yb))
+    worst_b, bad_b, n_b = (None, 0.0), [], 0
+    for name, p in m.named_parameters():
+        if name not in bn or P[name].grad is None:
+            continue
+        a, b = p.grad.float().cpu(), P[name].grad
+        rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+        cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+        n_b += 1
+        if rel > worst_b[1]:
+            worst_b = (name, rel)
+        if not (rel < (0.05 if "relative_position_bias_table" in name else 0.04) and cos > 0.995):
+            bad_b.append((name, round(rel, 4), round(cos, 5)))
+    print("Swin stage-2 block: tensors checked", n_b, "worst", worst_b, "out of tolerance", bad_b)
+    assert n_b >= 13 and not bad_b, bad_b
