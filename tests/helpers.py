@@ -64,13 +64,13 @@ def make_args(swin, bert, B, size_img=224, **kw):
     return a
 
 
-def build_filled_model(swin, bert, B, device="cuda", cls=None):
+def build_filled_model(swin, bert, B, device="cuda", cls=None, size_img=224):
     """LAVENDER_Pretrain_MLM (or `cls`) with every parameter filled deterministically from its key (same fill as the
     oracle)."""
     import torch
     from lavender_amd import LAVENDER_Pretrain_MLM
     from oracle import lavender_ref as R
-    m = (cls or LAVENDER_Pretrain_MLM)(make_args(swin, bert, B), Tok())
+    m = (cls or LAVENDER_Pretrain_MLM)(make_args(swin, bert, B, size_img=size_img), Tok())
     sd = m.state_dict()
     new = {k: R.fill_tensor(k, v.shape) for k, v in sd.items() if v.is_floating_point()}
     new["fc_mtm.predictions.decoder.bias"] = new["fc_mtm.predictions.bias"]

@@ -324,8 +324,11 @@ def test_keep_logits_flag_leaves_the_outputs_intact_and_the_gradients_equal():
     assert abs(res[0][0] - res[1][0]) < 1e-4 and rel < 1e-4, (res[0][0], res[1][0], rel)
 
 
-def test_base_12l_backward_at_the_benchmark_batch_cut_graph_vs_oracle():
-    """A BACKWARD check at the shape bench.py times (B = 32: 160 fusion sequences of 282 tokens, M = 45120 GEMMs with the step's tile / split-K /
+@pytest.mark.parametrize("swin, S, B", [("base", 224, 32), ("large", 384, 8)], ids=["cfg2_b32", "cfg4_b8"])
+def test_12l_backward_at_the_benchmark_batch_cut_graph_vs_oracle(swin, S, B):
+    """(cfg2_b32 in the words below; cfg4_b8 is the same at the side workload's bench shape: Swin-L, 5 x 384^2, B = 8 -- 40 fusion sequences of 757 tokens on
+    the chunked sequence kernels, 720-token windows on the large-window kernels.)
+    A BACKWARD check at the shape bench.py times (B = 32: 160 fusion sequences of 282 tokens, M = 45120 GEMMs with the step's tile / split-K /
     grouped weight-gradient choices, 1920-problem attention backward, 5120 x 30522 cross-entropy).  The whole model's oracle backward at this batch
     needs ~5 GB of fp32 autograd state per sample on the host, so the graph is CUT: the GPU runs the full eval-mode forward + backward; the input of the
     LAST fusion layer is captured on the way (its saved pre-LayerNorm rows, normalised on the host in fp32) and the oracle runs that layer + the MLM head +
@@ -337,9 +340,9 @@ def test_base_12l_backward_at_the_benchmark_batch_cut_graph_vs_oracle():
     from tests.helpers import build_filled_model
     from lavender_amd.agent import CrossEntropyIgnore
     import lavender_amd.engine as E
-    R, P, batch, bc = _oracle_case("base", "b12l", 32)
+    R, P, batch, bc = _oracle_case(swin, "b12l", B, S=S)
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    m = build_filled_model("base", "b12l", 32).eval()
+    m = build_filled_model(swin, "b12l", B, size_img=S).eval()
     ar = m.arena()
     last = m.trsfr.layer[-1]
     seen = {}
@@ -381,7 +384,7 @@ def test_base_12l_backward_at_the_benchmark_batch_cut_graph_vs_oracle():
     assert seen and seen["x32"] is not None, "the last fusion layer was not reached through the recomputed-LayerNorm residual path"
     pre, mean, rstd, gamma, beta = (t.float().cpu() for t in seen["x32"])
     n, L, Hd = seen["n"], seen["L"], pre.shape[1]
-    assert (n, L) == (160, 282)
+    assert (n, L) == ((160, 282) if swin == "base" else (40, 757))
     x_in = (((pre - mean[:, None]) * rstd[:, None]) * gamma + beta).view(n, L, Hd)
     km = seen["km"].cpu().long()
     names = [k for k in P if k.startswith(f"trsfr.layer.{len(m.trsfr.layer) - 1}.") or k.startswith("fc_mtm.")]
@@ -391,7 +394,7 @@ def test_base_12l_backward_at_the_benchmark_batch_cut_graph_vs_oracle():
     Lv = L - X
     hid = R.bert_layer(P, f"trsfr.layer.{len(m.trsfr.layer) - 1}", x_in, R.extended_mask(km), bc["heads"])
     logits = R.mlm_head(P, hid[:, Lv:])
-    ref = dict(out_mtm=logits[:32], out_vtm=logits[32:], ans_mtm=batch["ans_mtm"], ans_vtm=out["ans_vtm"].cpu())
+    ref = dict(out_mtm=logits[:B], out_vtm=logits[B:], ans_mtm=batch["ans_mtm"], ans_vtm=out["ans_vtm"].cpu())
     l1, l2 = R.pretrain_loss(ref)
     (l1 + l2).backward()
     assert abs((l1 + l2).item() - ls.item()) < 2e-2
