@@ -1049,6 +1049,95 @@ __global__ __launch_bounds__(512) void win_dbias3(AttnArgs a, int bsplit, const 
     const int nw_ = 2 * cw - 1, nh_ = 2 * ch - 1;
     const int ncls = (2 * dv - 1) * nh_ * nw_;
     const int q_lo = qh * 128;
+    // Two-stage class sums (round 5; the one-stage loop below took 33 of the kernel's ~75 us at the stage-2 shape: each thread walked the whole
+    // (d, h, w) box of its classes, 840 predicated LDS reads for ~64 useful ones).  The offset class of (q, k) is (row(q) - row(k) as a (d, h) pair,
+    // w(q) - w(k)): stage A sums every (query row, key row) block of cw x cw entries along its 2 cw - 1 diagonals -- each matrix entry is read
+    // once, <= cw reads per output --, stage B sums the (query row, key row) pairs of a class.  Z aliases the matrix (outputs wait in registers
+    // across a barrier).  Falls through to the one-stage loop for geometries whose stage-A table would not fit 20 outputs per thread.
+    {
+        const int q_hi = min(q_lo + 128, N);
+        const int R0 = q_lo / cw, R1 = q_hi > q_lo ? (q_hi - 1) / cw : R0 - 1;
+        const int nR = R1 - R0 + 1, nK = (N + cw - 1) / cw;
+        const int nout = nR * nK * nw_;
+        constexpr int MAXO = 20;
+        if (cw == 7 && nout <= 32768) {
+            // Swin's 7-wide rows: a thread takes whole (query row, key row) blocks -- 49 entries, 13 diagonal sums in registers, two
+            // integer divisions per block instead of four per output (stage A as written below spent 12 of its 12 us on index arithmetic)
+            float zb[2][13];
+            const int nblk = nR * nK;                         // <= 20 x 37
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int bI = tid + o * 512;
+#pragma unroll
+                for (int d = 0; d < 13; ++d) zb[o][d] = 0.f;
+                if (bI < nblk) {
+                    const int Rl = bI / nK, Kr = bI - Rl * nK;
+                    const int qb = (R0 + Rl) * 7, kb = Kr * 7;
+#pragma unroll
+                    for (int qw = 0; qw < 7; ++qw) {
+                        const int qq = qb + qw;
+                        const bool qv = qq >= q_lo && qq < q_hi;
+                        const float* row = Dm + (qv ? qq - q_lo : 0) * DLD + kb;
+#pragma unroll
+                        for (int kw = 0; kw < 7; ++kw)
+                            if (qv && kb + kw < N) zb[o][qw - kw + 6] += row[kw];
+                    }
+                }
+            }
+            __syncthreads();
+            float* Z = (float*)smem;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int bI = tid + o * 512;
+                if (bI < nblk) {
+#pragma unroll
+                    for (int d = 0; d < 13; ++d) Z[bI * 13 + d] = zb[o][d];
+                }
+            }
+            __syncthreads();
+        } else if (nout <= 512 * MAXO) {
+            float z[MAXO];
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o) {
+                const int idx = tid + o * 512;
+                float acc = 0.f;
+                if (idx < nout) {
+                    const int dwi = idx % nw_, t = idx / nw_;
+                    const int Kr = t % nK, Rl = t / nK;
+                    const int dw = dwi - (cw - 1);
+                    const int qb = (R0 + Rl) * cw, kb = Kr * cw - dw;
+                    for (int qw = max(0, dw); qw < min(cw, cw + dw); ++qw) {
+                        const int qq = qb + qw, kk = kb + qw;
+                        if (qq >= q_lo && qq < q_hi && kk < N) acc += Dm[(qq - q_lo) * DLD + kk];
+                    }
+                }
+                z[o] = acc;
+            }
+            __syncthreads();                                 // every thread has read its matrix entries: Z may overwrite them
+            float* Z = (float*)smem;
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o)
+                if (tid + o * 512 < nout) Z[tid + o * 512] = z[o];
+            __syncthreads();
+        }
+        if ((cw == 7 && nout <= 32768) || nout <= 512 * MAXO) {
+            const float* Z = (const float*)smem;
+            for (int c = tid; c < ncls; c += 512) {
+                const int dwi = c % nw_, dh = (c / nw_) % nh_ - (ch - 1), dd = c / (nw_ * nh_) - (dv - 1);
+                float p0 = 0.f, p1 = 0.f;
+                for (int qd = max(0, dd); qd < min(dv, dv + dd); ++qd)
+                    for (int qhh = max(0, dh); qhh < min(ch, ch + dh); ++qhh) {
+                        const int R = qd * ch + qhh, Kr = (qd - dd) * ch + (qhh - dh);
+                        if (R < R0 || R > R1 || Kr >= nK) continue;
+                        const float v = Z[((R - R0) * nK + Kr) * nw_ + dwi];
+                        if ((qhh & 1) == 0) p0 += v; else p1 += v;
+                    }
+                const float sum = p0 + p1;
+                if (sum != 0.f) atomicAdd(a.dbias + (long)(dd * a.cstride_d + dh * a.cstride_h + (dwi - (cw - 1)) + a.tbl_const) * a.d.heads + g.head, sum);
+            }
+            return;
+        }
+    }
     for (int c = tid; c < ncls; c += 512) {
         const int dw = c % nw_ - (cw - 1), dh = (c / nw_) % nh_ - (ch - 1), dd = c / (nw_ * nh_) - (dv - 1);   // offset = q - k
         const int koff = dd * chw + dh * cw + dw;
