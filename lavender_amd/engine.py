@@ -154,6 +154,7 @@ def _arm_join():
 def dw_join(device=None):
     """main stream waits for every weight-gradient kernel issued so far (before the gradients are read); the LayerNorm column
     reductions queued on the main stream (lav_layernorm_set_defer) are completed first."""
+    _join_armed[0] = False                                    # (also when called directly: a backward that raised never ran its callback)
     if torch.cuda.is_available():
         K.layernorm_flush()
     for dev, st in _dw_streams.items():
