@@ -87,79 +87,95 @@ __global__ __launch_bounds__(256) void video_embed_fwd_kernel(int B, int T, int 
     if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
 }
 
-// backward: one block per (token position p' (0 = cls), frame t): it walks the B rows that share the position and length
-// embeddings, so d_pos[p'], d_len[t], dgamma and dbeta are private register sums (one atomic per element per block
-// instead of one per row).
+// backward: one block per (token position p' (0 = cls), frame t); its four waves take the B rows that share the position and length
+// embeddings round-robin, a row per wave: 16-byte accesses (a lane owns 8-column chunks lane, lane + 64), row statistics by wave
+// reductions -- no block barrier in the row loop (round 5: the first form walked the rows one by one with 2-byte loads and two
+// __syncthreads per row: 236 us for 37 MB).  d_pos[p'], d_len[t], dgamma and dbeta are register sums per wave, merged through LDS: one atomic
+// per element per block.
 __global__ __launch_bounds__(256) void video_embed_bwd_kernel(int B, int T, int hw, int Hd, const bf16_t* __restrict__ dout, long seq_rows,
                                                              const bf16_t* __restrict__ feat, const float* cls, const float* pos,
                                                              const float* len, const float* gamma, const float* mean_i,
                                                              const float* rstd_i, bf16_t* __restrict__ dfeat, float* d_cls, float* d_pos,
                                                              float* d_len, float* dgamma, float* dbeta) {
-    __shared__ float red[2][4];
-    const int P = 1 + hw, pp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t_only = blockIdx.y;                        // one block per (position, frame): 5x more blocks than one per position
-    constexpr int MAXJ = 4;                               // columns per thread: Hd <= 1024
-    float xpos[MAXJ], gam[MAXJ], a_pos[MAXJ], a_g[MAXJ], a_b[MAXJ];
+    __shared__ float red[3][3][1024];                        // waves 1..3: (d_pos = d_len sum, dgamma, dbeta) per column
+    const int P = 1 + hw, pp = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int MAXC = 2;                                   // 8-column chunks per lane: Hd <= 1024
+    float xe[MAXC][8], gam[MAXC][8], a_x[MAXC][8], a_g[MAXC][8], a_b[MAXC][8];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int c = tid + 256 * j;
-        const bool ok = c < Hd;
-        xpos[j] = ok ? pos[(long)pp * Hd + c] + (pp == 0 ? cls[c] : 0.f) : 0.f;
-        gam[j] = ok ? gamma[c] : 0.f;
-        a_pos[j] = a_g[j] = a_b[j] = 0.f;
+    for (int it = 0; it < MAXC; ++it) {
+        const int col = (it * 64 + lane) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool ok = col < Hd;
+            xe[it][k] = ok ? pos[(long)pp * Hd + col + k] + (pp == 0 ? cls[col + k] : 0.f) + len[(long)t * Hd + col + k] : 0.f;
+            gam[it][k] = ok ? gamma[col + k] : 0.f;
+            a_x[it][k] = a_g[it][k] = a_b[it][k] = 0.f;
+        }
     }
-    for (int t = t_only; t == t_only; ++t) {
-        float a_len[MAXJ] = {0.f, 0.f, 0.f, 0.f};
-        float lent[MAXJ];
+    for (int b = wave; b < B; b += 4) {
+        const int bt = b * T + t;
+        const long r = (long)bt * P + pp;
+        const float mean = mean_i[r], rstd = rstd_i[r];
+        const bf16_t* dy = dout + ((long)b * seq_rows + (long)t * P + pp) * Hd;
+        const bf16_t* fr = feat + ((long)bt * hw + (pp > 0 ? pp - 1 : 0)) * Hd;
+        float xh[MAXC][8], gy[MAXC][8];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) { const int c = tid + 256 * j; lent[j] = c < Hd ? len[(long)t * Hd + c] : 0.f; }
-        for (int b = 0; b < B; ++b) {
-            const int bt = b * T + t;
-            const long r = (long)bt * P + pp;
-            const float mean = mean_i[r], rstd = rstd_i[r];
-            const bf16_t* dy = dout + ((long)b * seq_rows + (long)t * P + pp) * Hd;
-            float xh[MAXJ], gy[MAXJ], d[MAXJ];
-            float s1 = 0.f, s2 = 0.f;
+        for (int it = 0; it < MAXC; ++it) {
+            const int col = (it * 64 + lane) * 8;
+            if (col < Hd) {
+                float d[8], f[8];
+                unpack8(*(const uint4*)(dy + col), d);
+                if (pp > 0) unpack8(*(const uint4*)(fr + col), f);
 #pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                const int c = tid + 256 * j;
-                xh[j] = gy[j] = d[j] = 0.f;
-                if (c < Hd) {
-                    const float f = pp == 0 ? 0.f : bf2f(feat[((long)bt * hw + pp - 1) * Hd + c]);
-                    d[j] = bf2f(dy[c]);
-                    xh[j] = (f + xpos[j] + lent[j] - mean) * rstd;
-                    gy[j] = gam[j] * d[j];
-                    s1 += gy[j]; s2 += gy[j] * xh[j];
-                    a_g[j] += d[j] * xh[j]; a_b[j] += d[j];
-                }
-            }
-            s1 = wave_sum(s1); s2 = wave_sum(s2);
-            __syncthreads();
-            if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
-            __syncthreads();
-            const float m1 = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / Hd;
-            const float m2 = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / Hd;
-#pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                const int c = tid + 256 * j;
-                if (c < Hd) {
-                    const float dx = rstd * (gy[j] - m1 - xh[j] * m2);
-                    a_pos[j] += dx; a_len[j] += dx;
-                    if (pp > 0) dfeat[((long)bt * hw + pp - 1) * Hd + c] = f2bf(dx);
+                for (int k = 0; k < 8; ++k) {
+                    xh[it][k] = ((pp > 0 ? f[k] : 0.f) + xe[it][k] - mean) * rstd;
+                    gy[it][k] = gam[it][k] * d[k];
+                    s1 += gy[it][k]; s2 += gy[it][k] * xh[it][k];
+                    a_g[it][k] += d[k] * xh[it][k]; a_b[it][k] += d[k];
                 }
             }
         }
+        const float m1 = wave_sum(s1) / Hd, m2 = wave_sum(s2) / Hd;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) { const int c = tid + 256 * j; if (c < Hd) atomicAdd(d_len + (long)t * Hd + c, a_len[j]); }
+        for (int it = 0; it < MAXC; ++it) {
+            const int col = (it * 64 + lane) * 8;
+            if (col < Hd) {
+                float dx[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { dx[k] = rstd * (gy[it][k] - m1 - xh[it][k] * m2); a_x[it][k] += dx[k]; }
+                if (pp > 0) *(uint4*)(dfeat + ((long)bt * hw + pp - 1) * Hd + col) = pack8(dx);
+            }
+        }
     }
+    // merge the four waves' column sums, then one atomic per element per block
+    if (wave > 0) {
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int c = tid + 256 * j;
-        if (c < Hd) {
-            atomicAdd(d_pos + (long)pp * Hd + c, a_pos[j]);
-            if (pp == 0) atomicAdd(d_cls + c, a_pos[j]);
-            atomicAdd(dgamma + c, a_g[j]);
-            atomicAdd(dbeta + c, a_b[j]);
+        for (int it = 0; it < MAXC; ++it) {
+            const int col = (it * 64 + lane) * 8;
+            if (col < Hd)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { red[wave - 1][0][col + k] = a_x[it][k]; red[wave - 1][1][col + k] = a_g[it][k]; red[wave - 1][2][col + k] = a_b[it][k]; }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int it = 0; it < MAXC; ++it) {
+            const int col = (it * 64 + lane) * 8;
+            if (col < Hd)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int c = col + k;
+                    const float sx = a_x[it][k] + red[0][0][c] + red[1][0][c] + red[2][0][c];
+                    const float sg = a_g[it][k] + red[0][1][c] + red[1][1][c] + red[2][1][c];
+                    const float sb = a_b[it][k] + red[0][2][c] + red[1][2][c] + red[2][2][c];
+                    atomicAdd(d_len + (long)t * Hd + c, sx);
+                    atomicAdd(d_pos + (long)pp * Hd + c, sx);
+                    if (pp == 0) atomicAdd(d_cls + c, sx);
+                    atomicAdd(dgamma + c, sg);
+                    atomicAdd(dbeta + c, sb);
+                }
         }
     }
 }
